@@ -1,0 +1,40 @@
+// Common device helpers for the gfx950 (MI355X / CDNA4) kernels of p2pfl_amd.
+// Wavefront = 64 lanes everywhere in this tree; there is no other target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define P2PFL_API extern "C" __attribute__((visibility("default")))
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// 8 fp32 -> 8 bf16 (RNE; hipcc lowers the casts to v_cvt_pk_bf16_f32 on gfx950).
+__device__ __forceinline__ bf16x8 pack_bf16x8(const float* v) {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (__bf16)v[i];
+    return r;
+}
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// Every launcher returns the hipError_t of its launch as an int (0 == ok) so the
+// Python side can fail loudly instead of silently continuing.
+#define P2PFL_RETURN_LAST_ERROR() return (int)hipGetLastError()

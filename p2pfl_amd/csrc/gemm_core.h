@@ -1,0 +1,178 @@
+// Functor-driven MFMA tile GEMM for gfx950.
+//
+//   C[m][n] = sum_k A[m][k] * B[n][k]          (both operands presented "k-contiguous")
+//
+// Operands are produced by *loader functors* (arbitrary addressing: plain row-major,
+// transposed, im2col gathers, pool-routed gradients ...) as fp32, rounded to bf16 on
+// the way into LDS, multiplied on the matrix cores with
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulate) and handed tile-by-tile to an
+// *epilogue functor* (bias/ReLU/pool/optimizer fusions live there).
+//
+// Geometry (64-lane waves):  block = WR x WC waves, block tile BM x BN, BK = 32.
+// Each wave owns (BM/WR) x (BN/WC) outputs = RM x RN tiles of 32x32.
+// LDS rows hold 32 bf16 + 8 pad (80 B): every 16-lane ds_read_b128 group lands on 16
+// distinct 16-B slots of the 256-B bank row, so fragment reads are conflict-free.
+// Staging is register-split (issue global loads for tile t+1, run the MFMAs of tile t,
+// then write t+1 into the other LDS buffer): one barrier per K-step.
+//
+// Loader contract:
+//   static constexpr bool ROW_CONTIG;   // true: consecutive lanes -> consecutive rows
+//                                       // false: consecutive lanes -> consecutive k-chunks of a row
+//   __device__ void load8(int row, int k, float (&v)[8]) const;  // row,k global; k % 8 == 0;
+//                                       // must zero-fill anything out of range
+// Epilogue contract:
+//   __device__ void operator()(const f32x16& acc, int m0, int n0) const;
+//       lane l holds column n0 + (l & 31), rows m0 + (reg&3) + 8*(reg>>2) + 4*(l>>5).
+#pragma once
+#include "common.h"
+
+constexpr int GEMM_BK = 32;
+constexpr int GEMM_LDK = 40;  // bf16 elements per LDS row (32 data + 8 pad)
+
+__device__ __forceinline__ int mfma_row(int reg, int lane) {
+    return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+}
+
+template <int ROWS, int NT, class Loader>
+struct TileStager {
+    static constexpr int CHUNKS = ROWS * 4;                    // 16-B (8 x bf16) chunks per tile
+    static constexpr int PER_THREAD = (CHUNKS + NT - 1) / NT;  // chunks each thread moves
+    float v[PER_THREAD][8];
+
+    __device__ __forceinline__ static void decode(int c, int& row, int& k8) {
+        if (Loader::ROW_CONTIG) { row = c % ROWS; k8 = c / ROWS; }
+        else                    { row = c >> 2;   k8 = c & 3; }
+    }
+    __device__ __forceinline__ void load(const Loader& ld, int row0, int k0) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            int c = threadIdx.x + i * NT;
+            if (CHUNKS % NT == 0 || c < CHUNKS) {
+                int row, k8; decode(c, row, k8);
+                ld.load8(row0 + row, k0 + k8 * 8, v[i]);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(__bf16* lds) const {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            int c = threadIdx.x + i * NT;
+            if (CHUNKS % NT == 0 || c < CHUNKS) {
+                int row, k8; decode(c, row, k8);
+                *reinterpret_cast<bf16x8*>(lds + row * GEMM_LDK + k8 * 8) = pack_bf16x8(v[i]);
+            }
+        }
+    }
+};
+
+template <int BM, int BN>
+struct GemmSmem {
+    __bf16 a[2][BM * GEMM_LDK];
+    __bf16 b[2][BN * GEMM_LDK];
+};
+
+// Runs one BM x BN block tile over k in [k_begin, k_end) (k_begin % 32 == 0; loaders
+// zero-fill past their own K extent). All threads of the block must call it.
+template <int BM, int BN, int WR, int WC, class AL, class BL, class EPI>
+__device__ __forceinline__ void gemm_block_tile(GemmSmem<BM, BN>& sm, const AL& al, const BL& bl,
+                                                const EPI& epi, int m0, int n0, int k_begin,
+                                                int k_end) {
+    constexpr int NT = 64 * WR * WC;
+    constexpr int TM = BM / WR, TN = BN / WC;
+    constexpr int RM = TM / 32, RN = TN / 32;
+    static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of 32x32");
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wr = wave / WC, wc = wave % WC;
+    const int r = lane & 31, h = lane >> 5;
+
+    f32x16 acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    TileStager<BM, NT, AL> sa;
+    TileStager<BN, NT, BL> sb;
+
+    sa.load(al, m0, k_begin);
+    sb.load(bl, n0, k_begin);
+    sa.store(sm.a[0]);
+    sb.store(sm.b[0]);
+    __syncthreads();
+
+    int cur = 0;
+    for (int k = k_begin; k < k_end; k += GEMM_BK) {
+        const bool has_next = (k + GEMM_BK) < k_end;
+        if (has_next) {
+            sa.load(al, m0, k + GEMM_BK);
+            sb.load(bl, n0, k + GEMM_BK);
+        }
+        const __bf16* as = sm.a[cur] + (wr * TM + r) * GEMM_LDK + h * 8;
+        const __bf16* bs = sm.b[cur] + (wc * TN + r) * GEMM_LDK + h * 8;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[RM], bfr[RN];
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * GEMM_LDK + kk * 16);
+#pragma unroll
+            for (int j = 0; j < RN; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * GEMM_LDK + kk * 16);
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (has_next) {
+            sa.store(sm.a[cur ^ 1]);
+            sb.store(sm.b[cur ^ 1]);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+            epi(acc[i][j], m0 + wr * TM + i * 32, n0 + wc * TN + j * 32);
+}
+
+// ---------------------------------------------------------------------------------------
+// Plain loaders
+// ---------------------------------------------------------------------------------------
+
+// src[row * ld + k], k contiguous. `vec` enables the float4 fast path; the host launcher
+// sets it only when ld % 4 == 0 and the base (incl. client stride) is 16-B aligned.
+struct LoadRowMajorK {
+    static constexpr bool ROW_CONTIG = false;
+    const float* src; int rows, kdim, ld; bool vec;
+    __device__ __forceinline__ void load8(int row, int k, float (&v)[8]) const {
+        if (vec && row < rows && k + 8 <= kdim) {
+            const float4* p = reinterpret_cast<const float4*>(src + (size_t)row * ld + k);
+            float4 a = p[0], b = p[1];
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+            v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = (row < rows && k + j < kdim) ? src[(size_t)row * ld + k + j] : 0.f;
+        }
+    }
+};
+
+// src[k * ld + row], row contiguous (the operand is stored transposed w.r.t. its GEMM role).
+struct LoadColMajorK {
+    static constexpr bool ROW_CONTIG = true;
+    const float* src; int rows, kdim, ld;
+    __device__ __forceinline__ void load8(int row, int k, float (&v)[8]) const {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            v[j] = (row < rows && k + j < kdim) ? src[(size_t)(k + j) * ld + row] : 0.f;
+    }
+};

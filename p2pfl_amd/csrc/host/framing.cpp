@@ -1,0 +1,111 @@
+// Host data-plane helpers for the TCP compatibility path.
+//
+//  * PARAMS fragmenter: splits a serialized model into BLOCK_SIZE frames
+//    "PARAMS" + payload ... + "\PARAMS" + zero padding, the wire format of
+//    fedstellar/communication_protocol.py:737-769, in ONE pass into ONE output buffer
+//    (the reference builds ~12.7k Python bytes objects for a 26 MB model).
+//  * Reassembler: appends fragment payloads into a pre-sized growing buffer (amortised O(n);
+//    the reference concatenates bytes objects, O(n^2): node_connection.py:341-348).
+//  * Message-id ring: fixed-capacity "have I seen this gossip id" set
+//    (communication_protocol.py:146-160) with O(1) lookup.
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <unordered_set>
+#include <vector>
+
+#define API extern "C" __attribute__((visibility("default")))
+
+namespace {
+const char HDR[] = "PARAMS";        // 6 bytes
+const char END[] = "\\PARAMS";      // 7 bytes
+constexpr size_t HDR_LEN = 6, END_LEN = 7;
+}  // namespace
+
+// Number of frames build_params produces for `n` payload bytes.
+API size_t p2pfl_params_frame_count(size_t n, size_t block) {
+    if (block <= HDR_LEN + END_LEN) return 0;
+    const size_t cap = block - HDR_LEN;
+    size_t frames = n ? (n + cap - 1) / cap : 1;
+    const size_t last = n ? n - (frames - 1) * cap : 0;
+    if (HDR_LEN + last + END_LEN > block) frames += 1;
+    return frames;
+}
+
+// Writes frames back to back into out (capacity >= frames*block); every frame except possibly
+// a lone trailing "PARAMS\PARAMS" is exactly `block` bytes. Returns total bytes written and the
+// length of the last frame through *last_len (the reference leaves a separate closing frame
+// unpadded).
+API size_t p2pfl_params_build(const uint8_t* data, size_t n, size_t block, uint8_t* out, size_t* last_len) {
+    const size_t cap = block - HDR_LEN;
+    size_t off = 0, w = 0, last = 0;
+    if (n == 0) { std::memcpy(out, HDR, HDR_LEN); w = HDR_LEN; last = 0; }
+    while (off < n) {
+        const size_t take = (n - off < cap) ? n - off : cap;
+        std::memcpy(out + w, HDR, HDR_LEN);
+        std::memcpy(out + w + HDR_LEN, data + off, take);
+        off += take;
+        last = take;
+        w += HDR_LEN + take;
+    }
+    if (HDR_LEN + last + END_LEN <= block) {
+        std::memcpy(out + w, END, END_LEN);
+        w += END_LEN;
+        const size_t frame_len = HDR_LEN + last + END_LEN;
+        std::memset(out + w, 0, block - frame_len);
+        w += block - frame_len;
+        *last_len = block;
+    } else {
+        std::memcpy(out + w, HDR, HDR_LEN);
+        std::memcpy(out + w + HDR_LEN, END, END_LEN);
+        w += HDR_LEN + END_LEN;
+        *last_len = HDR_LEN + END_LEN;
+    }
+    return w;
+}
+
+struct Reassembler {
+    std::vector<uint8_t> buf;
+};
+
+API Reassembler* p2pfl_reasm_new(size_t reserve) {
+    auto* r = new Reassembler();
+    r->buf.reserve(reserve);
+    return r;
+}
+API void p2pfl_reasm_free(Reassembler* r) { delete r; }
+API void p2pfl_reasm_append(Reassembler* r, const uint8_t* p, size_t n) { r->buf.insert(r->buf.end(), p, p + n); }
+API size_t p2pfl_reasm_size(Reassembler* r) { return r->buf.size(); }
+API const uint8_t* p2pfl_reasm_data(Reassembler* r) { return r->buf.data(); }
+API void p2pfl_reasm_clear(Reassembler* r) { r->buf.clear(); }
+
+struct IdRing {
+    size_t cap;
+    std::deque<uint64_t> order;
+    std::unordered_multiset<uint64_t> seen;
+    std::mutex mu;
+};
+
+API IdRing* p2pfl_idring_new(size_t cap) { auto* r = new IdRing(); r->cap = cap ? cap : 1; return r; }
+API void p2pfl_idring_free(IdRing* r) { delete r; }
+// Returns 1 if id was already present, else inserts it (evicting the oldest) and returns 0.
+API int p2pfl_idring_check_and_add(IdRing* r, uint64_t id) {
+    std::lock_guard<std::mutex> g(r->mu);
+    if (r->seen.count(id)) return 1;
+    r->order.push_back(id);
+    r->seen.insert(id);
+    while (r->order.size() > r->cap) {
+        auto it = r->seen.find(r->order.front());
+        if (it != r->seen.end()) r->seen.erase(it);
+        r->order.pop_front();
+    }
+    return 0;
+}
+API int p2pfl_idring_contains(IdRing* r, uint64_t id) {
+    std::lock_guard<std::mutex> g(r->mu);
+    return r->seen.count(id) ? 1 : 0;
+}
+API size_t p2pfl_idring_size(IdRing* r) { std::lock_guard<std::mutex> g(r->mu); return r->order.size(); }

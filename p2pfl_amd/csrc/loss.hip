@@ -1,0 +1,93 @@
+// Fused (log-)softmax + cross-entropy forward/backward, accuracy counters and confusion matrix
+// for every client of the shard in one launch (one 64-lane wave per client-batch of <= 64 rows
+// would under-fill the chip, so a block handles one client and each *lane* owns one sample row:
+// C <= 64 classes are walked serially in registers; the work is a few kFLOP and purely
+// launch-bound, which is why it is fused into one kernel at all).
+//
+// Semantics (reference: fedstellar/learning/pytorch/mnist/models/mlp.py:142,161,169-180 and
+// mnist/models/cnn.py:166-177): loss = mean_b CE(logits_b, y_b). The MLP applies log_softmax
+// before CrossEntropyLoss; log_softmax is idempotent, so one kernel serves both models.
+#include "common.h"
+
+namespace {
+
+struct CeArgs {
+    const float* logits; long l_cs;     // [K][B][C]
+    const int* labels;   long y_cs;     // [K][n_samples]
+    const int* sidx;     long s_cs;     // [K][B] sample gather (or null: identity)
+    float* dlogits;      long d_cs;     // [K][B][C]  (null on the evaluation path)
+    float* loss_sum;                    // [K]  += sum_b loss_b
+    int* correct;                       // [K]  += #(argmax == y)
+    int* count;                         // [K]  += n_valid
+    int* confusion;                     // [K][C][C] (row = target, col = prediction) or null
+    const int* n_valid;  long nv_cs;    // [K] rows of this batch that are real samples (or null: B)
+    int B, C;
+};
+
+__global__ __launch_bounds__(64) void softmax_ce_kernel(CeArgs a) {
+    const int c = blockIdx.x;
+    const int nv = a.n_valid ? min(a.n_valid[c * a.nv_cs], a.B) : a.B;
+    const float inv = nv > 0 ? 1.f / (float)nv : 0.f;
+    float lsum = 0.f; int lcorrect = 0;
+    for (int b = threadIdx.x; b < a.B; b += 64) {
+        const float* z = a.logits + c * a.l_cs + (size_t)b * a.C;
+        float* dz = a.dlogits ? a.dlogits + c * a.d_cs + (size_t)b * a.C : nullptr;
+        if (b >= nv) {
+            if (dz) for (int j = 0; j < a.C; ++j) dz[j] = 0.f;
+            continue;
+        }
+        const int sample = a.sidx ? a.sidx[c * a.s_cs + b] : b;
+        const int y = a.labels[c * a.y_cs + sample];
+        float mx = z[0]; int am = 0;
+        for (int j = 1; j < a.C; ++j) { const float v = z[j]; if (v > mx) { mx = v; am = j; } }
+        float se = 0.f;
+        for (int j = 0; j < a.C; ++j) se += expf(z[j] - mx);
+        const float lse = mx + logf(se);
+        lsum += lse - z[y];
+        lcorrect += (am == y);
+        if (dz) {
+            const float rs = 1.f / se;
+            for (int j = 0; j < a.C; ++j) {
+                const float p = expf(z[j] - mx) * rs;
+                dz[j] = (p - (j == y ? 1.f : 0.f)) * inv;
+            }
+        }
+        if (a.confusion) atomicAdd(a.confusion + ((size_t)c * a.C + y) * a.C + am, 1);
+    }
+    lsum = wave_reduce_sum(lsum);
+    float fc = wave_reduce_sum((float)lcorrect);
+    if (threadIdx.x == 0) {
+        a.loss_sum[c] += lsum;
+        a.correct[c] += (int)(fc + 0.5f);
+        a.count[c] += nv;
+    }
+}
+
+__global__ void zero_rows_kernel(float* base, long cs, int n, int K) {
+    const int c = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        base[c * cs + i] = 0.f;
+}
+
+}  // namespace
+
+P2PFL_API int p2pfl_softmax_ce(const float* logits, long l_cs, const int* labels, long y_cs,
+                               const int* sidx, long s_cs, float* dlogits, long d_cs,
+                               float* loss_sum, int* correct, int* count, int* confusion,
+                               const int* n_valid, long nv_cs, int K, int B, int C,
+                               hipStream_t stream) {
+    if (K <= 0 || B <= 0 || C <= 0) return -1;
+    CeArgs a{logits, l_cs, labels, y_cs, sidx, s_cs, dlogits, d_cs, loss_sum, correct, count,
+             confusion, n_valid, nv_cs, B, C};
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(K), dim3(64), 0, stream, a);
+    P2PFL_RETURN_LAST_ERROR();
+}
+
+// Zero `n` floats at base + c*cs for every client c (gradient regions that are accumulated
+// with atomics).
+P2PFL_API int p2pfl_zero_rows(float* base, long cs, int n, int K, hipStream_t stream) {
+    if (K <= 0 || n <= 0) return -1;
+    int bx = (n + 255) / 256; if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(zero_rows_kernel, dim3(bx, K), dim3(256), 0, stream, base, cs, n, K);
+    P2PFL_RETURN_LAST_ERROR();
+}

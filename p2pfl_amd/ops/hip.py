@@ -1,0 +1,241 @@
+"""ctypes bindings of ``libp2pfl_hip.so`` (the gfx950 kernels under ``p2pfl_amd/csrc``).
+
+Every wrapper takes torch tensors whose *leading* dimension is the client dimension; the
+client stride is ``t.stride(0)``, so views into the ``[clients, P]`` slabs
+(``slab[:, off:off+n].unflatten(1, shape)``) are passed without copies. Kernels are enqueued
+on the current torch HIP stream, so they compose with torch ops and can be captured into a
+hipGraph with ``torch.cuda.graph``.
+
+The library is mandatory on a GPU box: if it is missing, calls raise instead of silently
+falling back to eager PyTorch.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_float, c_int, c_long, c_void_p
+from typing import Optional
+
+import torch
+
+from .build import HIP_LIB
+
+_lib = None
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the kernel library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not HIP_LIB.exists():
+            raise HipKernelError(
+                f"{HIP_LIB} is missing: run `python -m p2pfl_amd.ops.build` (or __graft_entry__.build()) first")
+        _lib = ctypes.CDLL(str(HIP_LIB))
+        for name in dir(_Sig):
+            if name.startswith("p2pfl_"):
+                fn = getattr(_lib, name)
+                fn.argtypes = getattr(_Sig, name)
+                fn.restype = c_int
+    return _lib
+
+
+def available() -> bool:
+    return HIP_LIB.exists() and torch.cuda.is_available()
+
+
+P, L, I, F = c_void_p, c_long, c_int, c_float
+
+
+class _Sig:
+    p2pfl_linear_fwd = [P, L, P, L, P, L, P, L, I, I, I, I, I, P]
+    p2pfl_linear_dgrad = [P, L, P, L, P, L, P, L, I, I, I, I, P]
+    p2pfl_linear_wgrad = [P, L, P, L, P, L, P, L, I, I, I, I, P]
+    p2pfl_conv1_fwd = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, P]
+    p2pfl_conv1_wgrad = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, P]
+    p2pfl_conv2_fwd = [P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, P]
+    p2pfl_conv2_wgrad = [P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, P]
+    p2pfl_conv2_dgrad = [P, L, P, L, P, L, P, L, I, I, I, I, I, P]
+    p2pfl_softmax_ce = [P, L, P, L, P, L, P, L, P, P, P, P, P, L, I, I, I, P]
+    p2pfl_zero_rows = [P, L, I, I, P]
+    p2pfl_adam_step = [P, P, P, P, L, L, I, F, F, F, F, F, I, P]
+    p2pfl_sgdm_step = [P, P, P, L, L, I, F, F, F, P]
+    p2pfl_fedavg = [P, L, I, P, L, P, L, P, P, P, P, P, I, L, P]
+    p2pfl_aes128_ecb = [P, P, P, L, I, P]
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(code: int, what: str) -> None:
+    if code != 0:
+        raise HipKernelError(f"{what} failed with code {code}")
+
+
+def _t(t: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+    if not t.is_cuda:
+        raise HipKernelError("HIP kernels need tensors on the GPU")
+    if t.dtype != dtype:
+        raise HipKernelError(f"expected {dtype}, got {t.dtype}")
+    # all dims but the first must be densely packed
+    exp = 1
+    for size, stride in zip(reversed(t.shape[1:]), reversed(t.stride()[1:])):
+        if size != 1 and stride != exp:
+            raise HipKernelError(f"inner dimensions must be contiguous, got shape {tuple(t.shape)} stride {t.stride()}")
+        exp *= size
+    return t
+
+
+def _pc(t: Optional[torch.Tensor], dtype=torch.float32):
+    """(pointer, client stride in elements) of a [K, ...] tensor; (None, 0) for None."""
+    if t is None:
+        return None, 0
+    _t(t, dtype)
+    return t.data_ptr(), (t.stride(0) if t.dim() > 0 and t.shape[0] > 1 else (t.stride(0) if t.dim() > 0 else 0))
+
+
+# ----------------------------------------------------------------------------- linear
+def linear_fwd(x, w, b, y, relu: bool) -> None:
+    """y[k] = act(x[k] @ w[k].T + b[k]);  x [K,B,In], w [K,Out,In], b [K,Out], y [K,B,Out]."""
+    K, B, In = x.shape
+    Out = w.shape[1]
+    assert w.shape == (K, Out, In) and b.shape == (K, Out) and y.shape == (K, B, Out)
+    (xp, xs), (wp, ws), (bp, bs), (yp, ys) = _pc(x), _pc(w), _pc(b), _pc(y)
+    _chk(load().p2pfl_linear_fwd(xp, xs, wp, ws, bp, bs, yp, ys, K, B, In, Out, int(relu), _stream()),
+         "linear_fwd")
+
+
+def linear_dgrad(dy, w, act, dx) -> None:
+    """dx[k] = (dy[k] @ w[k]) * (act[k] > 0)   (act None: no mask)."""
+    K, B, Out = dy.shape
+    In = w.shape[2]
+    assert w.shape == (K, Out, In) and dx.shape == (K, B, In)
+    (dp, ds), (wp, ws), (ap, as_), (xp, xs) = _pc(dy), _pc(w), _pc(act), _pc(dx)
+    _chk(load().p2pfl_linear_dgrad(dp, ds, wp, ws, ap, as_, xp, xs, K, B, In, Out, _stream()), "linear_dgrad")
+
+
+def linear_wgrad(dy, x, dw, db) -> None:
+    """dw[k] = dy[k].T @ x[k];  db[k] = dy[k].sum(0)."""
+    K, B, Out = dy.shape
+    In = x.shape[2]
+    assert dw.shape == (K, Out, In) and db.shape == (K, Out)
+    (dp, ds), (xp, xs), (wp, ws), (bp, bs) = _pc(dy), _pc(x), _pc(dw), _pc(db)
+    _chk(load().p2pfl_linear_wgrad(dp, ds, xp, xs, wp, ws, bp, bs, K, B, In, Out, _stream()), "linear_wgrad")
+
+
+# ----------------------------------------------------------------------------- conv
+def conv1_fwd(data, sidx, w, bias, a1, code, ks: int) -> None:
+    """Stage-1 conv(1->F, ks x ks, same) + ReLU + 2x2 maxpool.
+
+    data [K,n,784] fp32, sidx [K,B] int32 or None, w [K,F,ks*ks], bias [K,F],
+    a1 [K,B,F,196] fp32 out, code [K,B,F,196] uint8 out.
+    """
+    K, B, Fm = a1.shape[0], a1.shape[1], a1.shape[2]
+    (dp, ds), (sp, ss), (wp, ws), (bp, bs), (ap, as_) = _pc(data), _pc(sidx, torch.int32), _pc(w), _pc(bias), _pc(a1)
+    cp, cs = _pc(code, torch.uint8)
+    _chk(load().p2pfl_conv1_fwd(dp, ds, sp, ss, wp, ws, bp, bs, ap, as_, cp, cs, K, B, Fm, ks, _stream()),
+         "conv1_fwd")
+
+
+def conv1_wgrad(g, code, data, sidx, dw, db, ks: int) -> None:
+    """Stage-1 weight/bias gradient (dw/db are zeroed here, then accumulated with atomics)."""
+    K, B, Fm = g.shape[0], g.shape[1], g.shape[2]
+    zero_rows(dw)
+    zero_rows(db)
+    (gp, gs), (dp, ds), (sp, ss), (wp, ws), (bp, bs) = _pc(g), _pc(data), _pc(sidx, torch.int32), _pc(dw), _pc(db)
+    cp, cs = _pc(code, torch.uint8)
+    _chk(load().p2pfl_conv1_wgrad(gp, gs, cp, cs, dp, ds, sp, ss, wp, ws, bp, bs, K, B, Fm, ks, _stream()),
+         "conv1_wgrad")
+
+
+def conv2_fwd(a1, w, bias, a2, code, ks: int) -> None:
+    """Stage-2 conv(Cin->Cout, ks x ks, same) + ReLU + 2x2 maxpool on the matrix cores.
+
+    a1 [K,B,Cin,196], w [K,Cout,Cin*ks*ks], bias [K,Cout], a2 [K,B,Cout,49], code uint8 like a2.
+    """
+    K, B, Cin = a1.shape[0], a1.shape[1], a1.shape[2]
+    Cout = w.shape[1]
+    (ap, as_), (wp, ws), (bp, bs), (op, os_) = _pc(a1), _pc(w), _pc(bias), _pc(a2)
+    cp, cs = _pc(code, torch.uint8)
+    _chk(load().p2pfl_conv2_fwd(ap, as_, wp, ws, bp, bs, op, os_, cp, cs, K, B, Cin, Cout, ks, _stream()),
+         "conv2_fwd")
+
+
+def conv2_wgrad(g, code, a1, dw, db, ks: int) -> None:
+    K, B, Cout = g.shape[0], g.shape[1], g.shape[2]
+    Cin = a1.shape[2]
+    (gp, gs), (ap, as_), (wp, ws), (bp, bs) = _pc(g), _pc(a1), _pc(dw), _pc(db)
+    cp, cs = _pc(code, torch.uint8)
+    _chk(load().p2pfl_conv2_wgrad(gp, gs, cp, cs, ap, as_, wp, ws, bp, bs, K, B, Cin, Cout, ks, _stream()),
+         "conv2_wgrad")
+
+
+def conv2_dgrad(g, code, w, da1, ks: int) -> None:
+    K, B, Cout = g.shape[0], g.shape[1], g.shape[2]
+    Cin = da1.shape[2]
+    (gp, gs), (wp, ws), (dp, ds) = _pc(g), _pc(w), _pc(da1)
+    cp, cs = _pc(code, torch.uint8)
+    _chk(load().p2pfl_conv2_dgrad(gp, gs, cp, cs, wp, ws, dp, ds, K, B, Cin, Cout, ks, _stream()), "conv2_dgrad")
+
+
+# ----------------------------------------------------------------------------- loss / misc
+def softmax_ce(logits, labels, sidx, dlogits, loss_sum, correct, count, confusion=None, n_valid=None) -> None:
+    """Fused softmax-CE fwd/bwd + metric counters. logits [K,B,C]; labels [K,n] int32."""
+    K, B, C = logits.shape
+    (lp, ls), (yp, ys), (sp, ss), (dp, ds) = _pc(logits), _pc(labels, torch.int32), _pc(sidx, torch.int32), _pc(dlogits)
+    nvp, nvs = _pc(n_valid, torch.int32)
+    _chk(load().p2pfl_softmax_ce(lp, ls, yp, ys, sp, ss, dp, ds, _t(loss_sum).data_ptr(),
+                                 _t(correct, torch.int32).data_ptr(), _t(count, torch.int32).data_ptr(),
+                                 None if confusion is None else _t(confusion, torch.int32).data_ptr(),
+                                 nvp, nvs, K, B, C, _stream()), "softmax_ce")
+
+
+def zero_rows(t) -> None:
+    """Zero a [K, ...] (possibly slab-strided) view."""
+    K = t.shape[0]
+    n = t[0].numel()
+    p, s = _pc(t)
+    _chk(load().p2pfl_zero_rows(p, s, n, K, _stream()), "zero_rows")
+
+
+# ----------------------------------------------------------------------------- optimizers
+def adam_step(p, g, m, v, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, t: int) -> None:
+    """One Adam step over [K, P] slabs that share one row stride."""
+    K, n = p.shape
+    cs = p.stride(0)
+    assert g.stride(0) == cs and m.stride(0) == cs and v.stride(0) == cs and g.shape == p.shape
+    _chk(load().p2pfl_adam_step(_t(p).data_ptr(), _t(g).data_ptr(), _t(m).data_ptr(), _t(v).data_ptr(), cs, n, K,
+                                lr, beta1, beta2, eps, weight_decay, t, _stream()), "adam_step")
+
+
+def sgdm_step(p, g, buf, *, lr, momentum=0.9, weight_decay=0.0) -> None:
+    K, n = p.shape
+    cs = p.stride(0)
+    assert g.stride(0) == cs and buf.stride(0) == cs and g.shape == p.shape
+    _chk(load().p2pfl_sgdm_step(_t(p).data_ptr(), _t(g).data_ptr(), _t(buf).data_ptr(), cs, n, K, lr, momentum,
+                                weight_decay, _stream()), "sgdm_step")
+
+
+# ----------------------------------------------------------------------------- FedAvg
+def fedavg(local, remote, out, src_ptr, src_row, src_w, dst_ptr, dst_row) -> None:
+    """Grouped weighted row reduce (see csrc/fedavg.hip). `remote` may be None."""
+    n_local, n = local.shape
+    G = src_ptr.numel() - 1
+    rp, rs = (remote.data_ptr(), remote.stride(0)) if remote is not None and remote.numel() else (local.data_ptr(), local.stride(0))
+    _chk(load().p2pfl_fedavg(_t(local).data_ptr(), local.stride(0), n_local, rp, rs, _t(out).data_ptr(),
+                             out.stride(0), _t(src_ptr, torch.int32).data_ptr(),
+                             _t(src_row, torch.int32).data_ptr(), _t(src_w).data_ptr(),
+                             _t(dst_ptr, torch.int32).data_ptr(), _t(dst_row, torch.int32).data_ptr(), G, n,
+                             _stream()), "fedavg")
+
+
+def aes128_ecb(src, dst, round_keys, decrypt: bool) -> None:
+    """AES-128-ECB over a flat uint8 buffer (length % 16 == 0) with expanded round keys [176] uint8."""
+    n = src.numel()
+    assert n % 16 == 0 and dst.numel() == n and round_keys.numel() == 176
+    _chk(load().p2pfl_aes128_ecb(_t(src, torch.uint8).data_ptr(), _t(dst, torch.uint8).data_ptr(),
+                                 _t(round_keys, torch.uint8).data_ptr(), n // 16, int(decrypt), _stream()),
+         "aes128_ecb")

@@ -1,0 +1,163 @@
+#!/usr/bin/env python
+"""Headline benchmark: federated rounds/sec + aggregate client samples/sec, MNIST CNN, 100 nodes
+(BASELINE.json). One "step" = one complete federated round of every node hosted by the job:
+
+    evaluate (test shard) -> local training (epochs x ceil(n_train/32) Adam steps, batch 32,
+    shuffled, + per-epoch validation) -> model exchange -> FedAvg over each node's train set.
+
+Launch:  python bench.py --gpus 1 --steps K --warmup W
+         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Scaling is weak by default: every GPU hosts ``--nodes-per-gpu`` (100) federation nodes of one
+N x 100-node random-topology scenario, so N = 1 is exactly the named 100-node configuration.
+Data is synthetic MNIST-shaped (reference shard sizes for a 100-node split: 540 train / 60 val /
+100 test per node), weights are random-init; compute is bf16 MFMA with fp32 accumulation, fp32
+master weights and fp32 Adam moments.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from p2pfl_amd.datasets.synthetic import reference_shard_sizes, synthetic_shards  # noqa: E402
+from p2pfl_amd.models.specs import get_spec  # noqa: E402
+from p2pfl_amd.runtime.federation import BatchedFederation  # noqa: E402
+from p2pfl_amd.utils.topologymanager import TopologyManager  # noqa: E402
+
+# measured with `python bench.py --impl eager` on one MI355X: the
+# reference-equivalent per-node eager PyTorch loop, client samples/sec on the same config
+EAGER_BASELINE_SAMPLES_PER_SEC = None
+
+
+def build_topology(kind: str, n: int, seed: int):
+    tm = TopologyManager(n_nodes=n, b_symmetric=True, undirected_neighbor_num=max(n - 1, 2) if kind == "fully" else 3,
+                         seed=seed)
+    if kind == "fully":
+        tm.generate_topology()
+    elif kind == "ring":
+        tm.generate_ring_topology()
+    elif kind == "star":
+        tm.generate_server_topology()
+    else:   # random: ring + seeded random links (mean degree ~4)
+        tm.generate_topology(extra_random_links=2.0)
+    return tm.topology
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nodes-per-gpu", type=int, default=100)
+    ap.add_argument("--model", default="mnist-cnn")
+    ap.add_argument("--topology", default="random", choices=["random", "ring", "fully", "star"])
+    ap.add_argument("--federation", default="DFL")
+    ap.add_argument("--epochs", type=int, default=3)
+    ap.add_argument("--batch-size", type=int, default=32)
+    ap.add_argument("--impl", default="hip", choices=["hip", "eager"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--encrypt", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cpu", action="store_true", help="debug: run on the CPU with gloo")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--split-nodes", type=int, default=100,
+                    help="data shards are sized as in an N-node split of MNIST (reference mnist.py:100-118)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.cpu:
+        device = torch.device("cpu")
+        args.impl = "eager"
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if args.cpu else "nccl", rank=rank, world_size=world,
+                                **({} if args.cpu else {"device_id": device}))
+        pg = dist.group.WORLD
+
+    n_nodes = args.nodes_per_gpu * world if args.scaling == "weak" else args.nodes_per_gpu
+    spec = get_spec(args.model)
+    topo = build_topology(args.topology, n_nodes, args.seed)
+    fed = BatchedFederation(spec, topo, federation=args.federation, device=device, engine=args.impl,
+                            batch_size=args.batch_size, epochs=args.epochs, seed=args.seed, rank=rank,
+                            world_size=world, process_group=pg, encrypt=args.encrypt,
+                            use_graph=not args.no_graph)
+    # shard sizes of the named 100-node split (reference mnist.py:100-118)
+    n_tr, n_va, n_te = reference_shard_sizes(args.split_nodes)
+    tx, ty, vx, vy, ex, ey = synthetic_shards(fed.n_local, n_tr, n_va, n_te, spec.num_classes, seed=args.seed,
+                                              device=device, first_client=fed.local.start)
+    fed.init_params()
+    fed.set_local_data(tx, ty, vx, vy, ex, ey)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        if device.type == "cuda":
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        fed.run_round(sync_timing=False)
+    sync()
+    t0 = time.perf_counter()
+    samples = 0
+    last = None
+    for _ in range(args.steps):
+        last = fed.run_round(sync_timing=False)
+        samples += last.train_samples
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    stats = torch.tensor([elapsed, float(samples)], dtype=torch.float64, device=device)
+    if world > 1:
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        ssum = stats[1:].clone()
+        dist.all_reduce(ssum, op=dist.ReduceOp.SUM)
+        elapsed, samples = float(tmax.item()), float(ssum.item())
+    if rank == 0:
+        sps = samples / elapsed
+        steps_per_epoch = -(-n_tr // args.batch_size)
+        out = {
+            "metric": "aggregate client samples/sec (federated rounds, MNIST CNN, 100 nodes per GPU)",
+            "value": sps,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": args.scaling,
+            "vs_baseline": (sps / (EAGER_BASELINE_SAMPLES_PER_SEC * world)) if EAGER_BASELINE_SAMPLES_PER_SEC else None,
+            "dtype": "bf16" if args.impl == "hip" else "fp32",
+            "data": "synthetic",
+            "rounds_per_sec": args.steps / elapsed,
+            "config": {
+                "model": spec.name, "impl": args.impl, "nodes": n_nodes, "nodes_per_gpu": fed.n_local,
+                "topology": args.topology, "federation": args.federation, "epochs": args.epochs,
+                "global_batch": args.batch_size * n_nodes, "batch_per_node": args.batch_size,
+                "train_samples_per_node": n_tr, "optimizer_steps_per_round": steps_per_epoch * args.epochs,
+                "seq_len": None, "parallelism": f"fdp{world}x{fed.n_local}", "encrypt": args.encrypt,
+                "last_test_accuracy_mean": None if last is None or last.test_accuracy is None
+                else float(last.test_accuracy.mean()),
+            },
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,7 @@ struct AdamArgs {
     float lr, beta1, beta2, eps, weight_decay;
     float inv_bc1;      // 1 / (1 - beta1^t)
     float inv_sqrt_bc2; // 1 / sqrt(1 - beta2^t)
+    const float* bc;    // optional device copy of {inv_bc1, inv_sqrt_bc2} (graph replay with varying t)
 };
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
@@ -22,7 +23,9 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     const float4* g = reinterpret_cast<const float4*>(a.g + row);
     float4* m = reinterpret_cast<float4*>(a.m + row);
     float4* v = reinterpret_cast<float4*>(a.v + row);
-    const float step = a.lr * a.inv_bc1;
+    const float inv_bc1 = a.bc ? a.bc[0] : a.inv_bc1;
+    const float inv_sqrt_bc2 = a.bc ? a.bc[1] : a.inv_sqrt_bc2;
+    const float step = a.lr * inv_bc1;
     const float omb1 = 1.f - a.beta1, omb2 = 1.f - a.beta2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (long)gridDim.x * 256) {
         float4 pv = p[i], gv = g[i], mv = m[i], vv = v[i];
@@ -32,7 +35,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
             float gr = gg[j] + a.weight_decay * pp[j];
             mm[j] = a.beta1 * mm[j] + omb1 * gr;
             vq[j] = a.beta2 * vq[j] + omb2 * gr * gr;
-            const float denom = sqrtf(vq[j]) * a.inv_sqrt_bc2 + a.eps;
+            const float denom = sqrtf(vq[j]) * inv_sqrt_bc2 + a.eps;
             pp[j] -= step * (mm[j] / denom);
         }
         p[i] = pv; m[i] = mv; v[i] = vv;
@@ -74,14 +77,14 @@ inline int grid_x(long n4, int K) {
 
 P2PFL_API int p2pfl_adam_step(float* p, const float* g, float* m, float* v, long cs, long n, int K,
                               float lr, float beta1, float beta2, float eps, float weight_decay,
-                              int t, hipStream_t stream) {
+                              int t, const float* bc, hipStream_t stream) {
     if (K <= 0 || n <= 0 || t <= 0) return -1;
     if ((n & 3) || (cs & 3) || ((uintptr_t)p & 15) || ((uintptr_t)g & 15) || ((uintptr_t)m & 15) ||
         ((uintptr_t)v & 15))
         return -2;
     const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
     AdamArgs a{p, g, m, v, cs, n / 4, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
-               (float)(1.0 / sqrt(bc2))};
+               (float)(1.0 / sqrt(bc2)), bc};
     hipLaunchKernelGGL(adam_kernel, dim3(grid_x(n / 4, K), K), dim3(256), 0, stream, a);
     P2PFL_RETURN_LAST_ERROR();
 }

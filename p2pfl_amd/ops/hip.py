@@ -60,7 +60,7 @@ class _Sig:
     p2pfl_conv2_dgrad = [P, L, P, L, P, L, P, L, I, I, I, I, I, P]
     p2pfl_softmax_ce = [P, L, P, L, P, L, P, L, P, P, P, P, P, L, I, I, I, P]
     p2pfl_zero_rows = [P, L, I, I, P]
-    p2pfl_adam_step = [P, P, P, P, L, L, I, F, F, F, F, F, I, P]
+    p2pfl_adam_step = [P, P, P, P, L, L, I, F, F, F, F, F, I, P, P]
     p2pfl_sgdm_step = [P, P, P, L, L, I, F, F, F, P]
     p2pfl_fedavg = [P, L, I, P, L, P, L, P, P, P, P, P, I, L, P]
     p2pfl_aes128_ecb = [P, P, P, L, I, P]
@@ -94,7 +94,7 @@ def _pc(t: Optional[torch.Tensor], dtype=torch.float32):
     if t is None:
         return None, 0
     _t(t, dtype)
-    return t.data_ptr(), (t.stride(0) if t.dim() > 0 and t.shape[0] > 1 else (t.stride(0) if t.dim() > 0 else 0))
+    return t.data_ptr(), (t.stride(0) if t.dim() > 0 else 0)
 
 
 # ----------------------------------------------------------------------------- linear
@@ -202,13 +202,17 @@ def zero_rows(t) -> None:
 
 
 # ----------------------------------------------------------------------------- optimizers
-def adam_step(p, g, m, v, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, t: int) -> None:
-    """One Adam step over [K, P] slabs that share one row stride."""
+def adam_step(p, g, m, v, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, t: int, bc=None) -> None:
+    """One Adam step over [K, P] slabs that share one row stride.
+
+    ``bc``: optional device tensor [2] = (1/(1-beta1^t), 1/sqrt(1-beta2^t)) read by the kernel at
+    run time instead of the host-computed scalars (lets a captured graph be replayed for any t)."""
     K, n = p.shape
     cs = p.stride(0)
     assert g.stride(0) == cs and m.stride(0) == cs and v.stride(0) == cs and g.shape == p.shape
     _chk(load().p2pfl_adam_step(_t(p).data_ptr(), _t(g).data_ptr(), _t(m).data_ptr(), _t(v).data_ptr(), cs, n, K,
-                                lr, beta1, beta2, eps, weight_decay, t, _stream()), "adam_step")
+                                lr, beta1, beta2, eps, weight_decay, t,
+                                None if bc is None else _t(bc).data_ptr(), _stream()), "adam_step")
 
 
 def sgdm_step(p, g, buf, *, lr, momentum=0.9, weight_decay=0.0) -> None:

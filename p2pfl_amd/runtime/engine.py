@@ -1,0 +1,483 @@
+"""Shard engines: local training / evaluation of ALL federation nodes resident on one device.
+
+The unit of execution is the *shard* (every virtual node of one GPU), not the node: parameters,
+gradients and optimizer moments are ``[K, P]`` slabs and every kernel carries a leading client
+dimension. Two interchangeable engines implement the same contract:
+
+* :class:`HipEngine`   – the MI355X path: hand-written gfx950 kernels (``p2pfl_amd/csrc``), a whole
+  local-training round (epochs x batches x {fwd, loss, bwd, optimizer}) captured into ONE hipGraph
+  and replayed per federated round. No autograd, no per-client Python.
+* :class:`EagerEngine` – one ``torch.nn`` module + ``torch.optim`` per client, looped in Python,
+  fp32. This is the behaviour-equivalent of the reference's per-node ``LightningLearner.fit``
+  (fedstellar/learning/pytorch/lightninglearner.py:113-143), serves as the CPU implementation,
+  as the numerical oracle of the HIP engine, and as the measured eager baseline of BASELINE.md.
+
+Both share the slab layout, so aggregation / exchange code is engine-agnostic.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+from ..models.specs import ModelSpec
+from ..models.torch_models import module_for_spec
+from .slab import ParamLayout
+
+PHASES = ("Train", "Validation", "Test")
+
+
+@dataclass
+class PhaseStats:
+    """Per-client accumulators of one phase (device tensors)."""
+    loss_sum: torch.Tensor     # [K] fp32
+    correct: torch.Tensor      # [K] int32
+    count: torch.Tensor        # [K] int32
+    confusion: torch.Tensor    # [K, C, C] int32 (row = target, col = prediction)
+
+    @staticmethod
+    def alloc(K: int, C: int, device) -> "PhaseStats":
+        return PhaseStats(torch.zeros(K, device=device), torch.zeros(K, dtype=torch.int32, device=device),
+                          torch.zeros(K, dtype=torch.int32, device=device),
+                          torch.zeros(K, C, C, dtype=torch.int32, device=device))
+
+    def zero_(self) -> None:
+        self.loss_sum.zero_(); self.correct.zero_(); self.count.zero_(); self.confusion.zero_()
+
+    def summary(self) -> Dict[str, torch.Tensor]:
+        cnt = self.count.clamp(min=1).float()
+        return {"loss": (self.loss_sum / cnt).cpu(), "accuracy": (self.correct.float() / cnt).cpu(),
+                "count": self.count.cpu(), "confusion": self.confusion.cpu()}
+
+
+class ShardEngine:
+    """Common state + contract of the two engines."""
+
+    def __init__(self, spec: ModelSpec, n_clients: int, device="cpu", batch_size: int = 32, seed: int = 0,
+                 persist_optimizer: bool = False):
+        self.spec = spec
+        self.K = int(n_clients)
+        self.device = torch.device(device)
+        self.B = int(batch_size)
+        self.seed = seed
+        self.persist_optimizer = persist_optimizer   # reference re-creates the optimizer every round
+        self.layout = ParamLayout(spec)
+        self.params = self.layout.alloc(self.K, self.device)
+        self.params_alt = None                        # aggregation output (allocated on first use)
+        self.stats = {ph: PhaseStats.alloc(self.K, spec.num_classes, self.device) for ph in PHASES}
+        self.gen = torch.Generator(device="cpu")
+        self.gen.manual_seed(seed)
+        self.train_x = self.train_y = self.val_x = self.val_y = self.test_x = self.test_y = None
+        self.opt_steps = 0
+
+    # ------------------------------------------------------------------ parameters
+    def init_params(self, seed: Optional[int] = None, identical: bool = True) -> None:
+        """PyTorch default initialisation; ``identical`` = every node starts from the start node's
+        weights (the reference's init-model diffusion, node.py:298-299,372-379)."""
+        seed = self.seed if seed is None else seed
+        if identical:
+            sd = module_for_spec(self.spec, seed=seed).state_dict()
+            row = torch.zeros(self.layout.row_stride)
+            self.layout.state_dict_to_row(sd, row)
+            self.params.copy_(row.to(self.device).unsqueeze(0).expand(self.K, -1))
+        else:
+            for k in range(self.K):
+                sd = module_for_spec(self.spec, seed=seed + k).state_dict()
+                self.layout.state_dict_to_row(sd, self.params[k])
+
+    def get_state_dict(self, k: int):
+        return self.layout.row_to_state_dict(self.params[k])
+
+    def set_state_dict(self, k: int, sd) -> None:
+        self.layout.state_dict_to_row(sd, self.params[k])
+
+    def alt_slab(self) -> torch.Tensor:
+        if self.params_alt is None:
+            self.params_alt = torch.zeros_like(self.params)
+        return self.params_alt
+
+    def swap_slabs(self) -> None:
+        """Make the aggregation output the live parameters. Engines that captured pointers into
+        ``params`` override this with a copy."""
+        self.params.copy_(self.alt_slab())
+
+    # ------------------------------------------------------------------ data
+    def set_data(self, train_x, train_y, val_x=None, val_y=None, test_x=None, test_y=None) -> None:
+        """``*_x`` [K, n, 784] fp32 (flattened 28x28, already normalised), ``*_y`` [K, n] integer."""
+        def put(x, y):
+            if x is None:
+                return None, None
+            x = x.reshape(self.K, x.shape[1], -1).to(self.device, torch.float32).contiguous()
+            y = y.to(self.device, torch.int32).contiguous()
+            return x, y
+        self.train_x, self.train_y = put(train_x, train_y)
+        self.val_x, self.val_y = put(val_x, val_y)
+        self.test_x, self.test_y = put(test_x, test_y)
+        self._on_data_changed()
+
+    def _on_data_changed(self) -> None:
+        pass
+
+    def num_samples(self):
+        n_tr = 0 if self.train_x is None else self.train_x.shape[1]
+        n_te = 0 if self.test_x is None else self.test_x.shape[1]
+        return n_tr, n_te
+
+    def steps_per_epoch(self) -> int:
+        return math.ceil(self.train_x.shape[1] / self.B)
+
+    def _epoch_perms(self, epochs: int) -> torch.Tensor:
+        """[epochs, K, steps*B] int32 shuffles (padded with wrapped indices; padded rows are masked)."""
+        n = self.train_x.shape[1]
+        steps = self.steps_per_epoch()
+        r = torch.rand(epochs, self.K, n, generator=self.gen)
+        perm = r.argsort(dim=2).to(torch.int32)
+        if steps * self.B != n:   # wrap around: the extra rows are masked out through n_valid
+            perm = perm[:, :, torch.arange(steps * self.B) % n]
+        return perm.contiguous()
+
+    # ------------------------------------------------------------------ contract
+    def reset_optimizer(self) -> None:
+        raise NotImplementedError
+
+    def fit(self, epochs: int, active: Optional[torch.Tensor] = None) -> Dict[str, Dict[str, torch.Tensor]]:
+        raise NotImplementedError
+
+    def evaluate(self) -> Dict[str, torch.Tensor]:
+        raise NotImplementedError
+
+    def synchronize(self) -> None:
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
+
+# ======================================================================================
+# Eager (reference-equivalent) engine
+# ======================================================================================
+class EagerEngine(ShardEngine):
+    """One ``nn.Module`` per client whose parameters alias the slab rows."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.modules: List[torch.nn.Module] = []
+        for k in range(self.K):
+            m = module_for_spec(self.spec).to(self.device)
+            for name, p in m.named_parameters():
+                p.data = self.layout.view(self.params, name)[k]
+            self.modules.append(m)
+        self.optims = None
+
+    def reset_optimizer(self) -> None:
+        self.optims = [m.configure_optimizers() for m in self.modules]
+        self.opt_steps = 0
+
+    def _run_phase(self, k, x, y, phase, train, optim=None, order=None):
+        m = self.modules[k]
+        st = self.stats[phase]
+        n = x.shape[0]
+        C = self.spec.num_classes
+        for s in range(0, n, self.B):
+            idx = order[s:s + self.B] if order is not None else torch.arange(s, min(s + self.B, n), device=self.device)
+            xb, yb = x[idx], y[idx].long()
+            if train:
+                out = m(xb)
+                loss = m.criterion(out, yb)
+                optim.zero_grad(set_to_none=True)
+                loss.backward()
+                optim.step()
+            else:
+                with torch.no_grad():
+                    out = m(xb)
+                    loss = m.criterion(out, yb)
+            pred = out.detach().argmax(dim=1)
+            st.loss_sum[k] += loss.detach() * len(idx)
+            st.correct[k] += (pred == yb).sum().to(torch.int32)
+            st.count[k] += len(idx)
+            st.confusion[k].view(-1).index_add_(0, (yb * C + pred), torch.ones_like(pred, dtype=torch.int32))
+
+    def fit(self, epochs, active=None):
+        if self.optims is None or not self.persist_optimizer:
+            self.reset_optimizer()
+        perms = self._epoch_perms(epochs).to(self.device).long()
+        n = self.train_x.shape[1]
+        hist = []
+        for e in range(epochs):
+            self.stats["Train"].zero_(); self.stats["Validation"].zero_()
+            for k in range(self.K):
+                if active is not None and not bool(active[k]):
+                    continue
+                self.modules[k].train()
+                self._run_phase(k, self.train_x[k], self.train_y[k], "Train", True, self.optims[k], perms[e, k, :n])
+                if self.val_x is not None:
+                    self.modules[k].eval()
+                    self._run_phase(k, self.val_x[k], self.val_y[k], "Validation", False)
+            hist.append({"Train": self.stats["Train"].summary(), "Validation": self.stats["Validation"].summary()})
+        self.opt_steps += epochs * self.steps_per_epoch()
+        return hist[-1] if hist else {}
+
+    def evaluate(self):
+        self.stats["Test"].zero_()
+        for k in range(self.K):
+            self.modules[k].eval()
+            self._run_phase(k, self.test_x[k], self.test_y[k], "Test", False)
+        return self.stats["Test"].summary()
+
+
+# ======================================================================================
+# HIP engine
+# ======================================================================================
+class HipEngine(ShardEngine):
+    """Client-batched gfx950 kernels + hipGraph replay (see module docstring)."""
+
+    def __init__(self, *a, use_graph: bool = True, **kw):
+        super().__init__(*a, **kw)
+        if self.device.type != "cuda":
+            raise RuntimeError("HipEngine needs a GPU device")
+        from ..ops import hip
+        hip.load()   # fail loudly if the kernels were not built
+        self.hip = hip
+        self.use_graph = use_graph
+        K, B, L = self.K, self.B, self.layout
+        dev = self.device
+        self.grads = L.alloc(K, dev)
+        o = self.spec.optim
+        self.m = L.alloc(K, dev)
+        self.v = L.alloc(K, dev) if o.kind == "adam" else None
+        # activations / activation gradients / pool codes per layer
+        self.act, self.dact, self.code = [], [], []
+        for l in self.spec.layers:
+            if l.kind == "conv1pool":
+                shp = (K, B, l.cout, 196)
+            elif l.kind == "conv2pool":
+                shp = (K, B, l.cout, 49)
+            else:
+                shp = (K, B, l.out_features)
+            self.act.append(torch.zeros(shp, device=dev))
+            self.dact.append(torch.zeros(shp, device=dev))
+            self.code.append(torch.zeros(shp, dtype=torch.uint8, device=dev) if l.kind != "linear" else None)
+        self.xin = torch.zeros(K, B, 784, device=dev) if self.spec.layers[0].kind == "linear" else None
+        self.karange = torch.arange(K, device=dev).unsqueeze(1)
+        self._nv_cache: Dict[int, torch.Tensor] = {}
+        self._tail_cache: Dict[tuple, torch.Tensor] = {}
+        self._graphs: Dict[tuple, tuple] = {}
+        self._perm_buf = None
+        self._bc_buf = None
+        self._eval_graph = None
+
+    # ------------------------------------------------------------------ helpers
+    def _w(self, slab, l):
+        return self.layout.view2d(slab, l.weight), self.layout.view(slab, l.bias)
+
+    def reset_optimizer(self) -> None:
+        self.m.zero_()
+        if self.v is not None:
+            self.v.zero_()
+        self.opt_steps = 0
+
+    def swap_slabs(self) -> None:
+        # captured graphs hold pointers into self.params: copy instead of swapping storages
+        self.params.copy_(self.alt_slab())
+
+    def _on_data_changed(self) -> None:
+        self._graphs.clear()
+        self._eval_graph = None
+
+    # ------------------------------------------------------------------ one batch
+    def _forward(self, data, sidx, labels, n_valid, phase: str, train: bool) -> None:
+        hip, layers = self.hip, self.spec.layers
+        x = None
+        for i, l in enumerate(layers):
+            W, b = self._w(self.params, l)
+            if l.kind == "conv1pool":
+                hip.conv1_fwd(data, sidx, W, b, self.act[i], self.code[i], l.ksize)
+            elif l.kind == "conv2pool":
+                hip.conv2_fwd(x, W, b, self.act[i], self.code[i], l.ksize)
+            else:
+                if x is None:
+                    if sidx is None:
+                        x = data[:, :self.B]
+                    else:
+                        self.xin.copy_(data[self.karange, sidx.long()])
+                        x = self.xin
+                hip.linear_fwd(x.flatten(2) if x.dim() > 3 else x, W, b, self.act[i], l.relu)
+            x = self.act[i]
+        st = self.stats[phase]
+        hip.softmax_ce(x, labels, sidx, self.dact[-1] if train else None, st.loss_sum, st.correct, st.count,
+                       st.confusion, n_valid)
+
+    def _backward(self, data, sidx) -> None:
+        hip, layers = self.hip, self.spec.layers
+        dy = self.dact[-1]
+        for i in range(len(layers) - 1, -1, -1):
+            l = layers[i]
+            W, _ = self._w(self.params, l)
+            gW, gb = self._w(self.grads, l)
+            if l.kind == "linear":
+                if i == 0:
+                    xin = self.xin if sidx is not None else data[:, :self.B]
+                else:
+                    xin = self.act[i - 1].flatten(2) if self.act[i - 1].dim() > 3 else self.act[i - 1]
+                hip.linear_wgrad(dy, xin, gW, gb)
+                if i > 0:
+                    prev = layers[i - 1]
+                    mask = self.act[i - 1] if (prev.kind == "linear" and prev.relu) else None
+                    dx = self.dact[i - 1].flatten(2) if self.dact[i - 1].dim() > 3 else self.dact[i - 1]
+                    hip.linear_dgrad(dy, W, mask, dx)
+                    dy = self.dact[i - 1]
+            elif l.kind == "conv2pool":
+                hip.conv2_wgrad(dy, self.code[i], self.act[i - 1], gW, gb, l.ksize)
+                hip.conv2_dgrad(dy, self.code[i], W, self.dact[i - 1], l.ksize)
+                dy = self.dact[i - 1]
+            else:  # conv1pool (first layer: no data gradient)
+                hip.conv1_wgrad(dy, self.code[i], data, sidx, gW, gb, l.ksize)
+
+    def _optim_step(self, step_index: int) -> None:
+        o = self.spec.optim
+        if o.kind == "adam":
+            self.hip.adam_step(self.params, self.grads, self.m, self.v, lr=o.lr, beta1=o.beta1, beta2=o.beta2,
+                               eps=o.eps, weight_decay=o.weight_decay, t=step_index,
+                               bc=self._bc_buf[step_index - 1] if self._bc_buf is not None else None)
+        else:
+            self.hip.sgdm_step(self.params, self.grads, self.m, lr=o.lr, momentum=o.momentum,
+                               weight_decay=o.weight_decay)
+
+    # ------------------------------------------------------------------ epochs
+    def _nv(self, value: int) -> torch.Tensor:
+        """Cached [K] int32 constant (static address: safe to bake into a captured graph)."""
+        t = self._nv_cache.get(value)
+        if t is None:
+            t = torch.full((self.K,), value, dtype=torch.int32, device=self.device)
+            self._nv_cache[value] = t
+        return t
+
+    def _tail_sidx(self, n: int, nb: int) -> torch.Tensor:
+        """Index list of the last partial evaluation batch: nb real rows, then clamped padding rows
+        (masked through n_valid) so every access stays inside the allocation."""
+        key = (n, nb)
+        t = self._tail_cache.get(key)
+        if t is None:
+            idx = torch.arange(n - nb, n - nb + self.B, device=self.device).clamp(max=n - 1).to(torch.int32)
+            t = idx.unsqueeze(0).expand(self.K, -1).contiguous()
+            self._tail_cache[key] = t
+        return t
+
+    def _eval_pass(self, x, y, phase: str) -> None:
+        n = x.shape[1]
+        for s in range(0, n, self.B):
+            nb = min(self.B, n - s)
+            if nb == self.B:
+                self._forward(x[:, s:], None, y[:, s:], self._nv(self.B), phase, train=False)
+            else:
+                self._forward(x, self._tail_sidx(n, nb), y, self._nv(nb), phase, train=False)
+
+    def _train_body(self, epochs: int, steps: int, n: int) -> None:
+        """Everything a local-training round launches (captured into one hipGraph)."""
+        nv_last = self._nv(n - (steps - 1) * self.B)
+        for ph in ("Train", "Validation"):
+            self.stats[ph].zero_()
+        t = 0
+        for e in range(epochs):
+            if e == epochs - 1 and epochs > 1:
+                for ph in ("Train", "Validation"):   # report the last epoch, like the per-epoch logs
+                    self.stats[ph].zero_()
+            for s in range(steps):
+                sidx = self._perm_buf[e, :, s * self.B:(s + 1) * self.B]
+                nv = nv_last if s == steps - 1 else self._nv(self.B)
+                self._forward(self.train_x, sidx, self.train_y, nv, "Train", train=True)
+                self._backward(self.train_x, sidx)
+                t += 1
+                self._optim_step(t)
+            if self.val_x is not None:
+                self._eval_pass(self.val_x, self.val_y, "Validation")
+
+    def fit(self, epochs, active=None):
+        if not self.persist_optimizer:
+            self.reset_optimizer()
+        n = self.train_x.shape[1]
+        steps = self.steps_per_epoch()
+        total = epochs * steps
+        perms = self._epoch_perms(epochs)
+        if self._perm_buf is None or self._perm_buf.shape != perms.shape:
+            self._perm_buf = torch.zeros(perms.shape, dtype=torch.int32, device=self.device)
+            self._graphs.clear()
+        self._perm_buf.copy_(perms, non_blocking=True)
+        # Adam bias corrections for steps t0+1 .. t0+total live in a device table, so one captured
+        # graph serves both the reference policy (fresh optimizer per round) and persistent moments.
+        o = self.spec.optim
+        if o.kind == "adam":
+            ts = torch.arange(self.opt_steps + 1, self.opt_steps + total + 1, dtype=torch.float64)
+            bc = torch.stack([1.0 / (1.0 - o.beta1 ** ts), 1.0 / torch.sqrt(1.0 - o.beta2 ** ts)], dim=1).float()
+            if self._bc_buf is None or self._bc_buf.shape != bc.shape:
+                self._bc_buf = torch.zeros(bc.shape, device=self.device)
+                self._graphs.clear()
+            self._bc_buf.copy_(bc, non_blocking=True)
+        saved = None
+        if active is not None and not bool(torch.as_tensor(active).all()):
+            inactive = (~torch.as_tensor(active, dtype=torch.bool)).nonzero().flatten().to(self.device)
+            saved = (inactive, self.params[inactive].clone())
+        if self.use_graph:
+            key = (epochs, steps, n)
+            if key not in self._graphs:
+                # warm-up on a side stream (lazy module loads, allocator), then capture
+                s = torch.cuda.Stream(device=self.device)
+                s.wait_stream(torch.cuda.current_stream())
+                snap = (self.params.clone(), self.m.clone(), None if self.v is None else self.v.clone())
+                with torch.cuda.stream(s):
+                    self._train_body(1, min(steps, 2), n)
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                self.params.copy_(snap[0]); self.m.copy_(snap[1])
+                if self.v is not None:
+                    self.v.copy_(snap[2])
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._train_body(epochs, steps, n)
+                self._graphs[key] = (g,)
+                self.params.copy_(snap[0]); self.m.copy_(snap[1])
+                if self.v is not None:
+                    self.v.copy_(snap[2])
+            self._graphs[key][0].replay()
+        else:
+            self._train_body(epochs, steps, n)
+        self.opt_steps += total
+        if saved is not None:
+            self.params[saved[0]] = saved[1]
+        out = {"Train": self.stats["Train"].summary()}
+        if self.val_x is not None:
+            out["Validation"] = self.stats["Validation"].summary()
+        return out
+
+    def _eval_body(self) -> None:
+        self.stats["Test"].zero_()
+        self._eval_pass(self.test_x, self.test_y, "Test")
+
+    def evaluate(self):
+        if self.use_graph:
+            if self._eval_graph is None:
+                s = torch.cuda.Stream(device=self.device)
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    self._eval_body()
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._eval_body()
+                self._eval_graph = g
+            self._eval_graph.replay()
+        else:
+            self._eval_body()
+        return self.stats["Test"].summary()
+
+
+def make_engine(spec: ModelSpec, n_clients: int, device, impl: str = "auto", **kw) -> ShardEngine:
+    """``impl``: "hip" | "eager" | "auto" (hip on a GPU, eager on the CPU)."""
+    device = torch.device(device)
+    if impl == "auto":
+        impl = "hip" if device.type == "cuda" else "eager"
+    if impl == "hip":
+        return HipEngine(spec, n_clients, device, **kw)
+    kw.pop("use_graph", None)
+    return EagerEngine(spec, n_clients, device, **kw)

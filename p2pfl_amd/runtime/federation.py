@@ -1,0 +1,393 @@
+"""BatchedFederation: hundreds of virtual federation nodes per GPU, one process per GPU.
+
+This is the MI355X-native execution model of the framework. Every rank (= one GPU) hosts a
+contiguous block of the scenario's nodes inside one :class:`ShardEngine`; a federated round is
+
+    evaluate  ->  local training (epochs)  ->  model exchange  ->  FedAvg  ->  bookkeeping
+
+which reproduces the per-node round of the reference (``Node.__train_step`` /
+``__on_round_finished``, fedstellar/node.py:402-535,632-674) for all nodes at once:
+
+* ``train_set(i)`` = live direct neighbours of i plus i itself (node.py:411-422,537-548);
+* aggregators / servers average their train set weighted by training-sample counts
+  (node.py:444-448, fedavg.py:40-60); a SERVER never trains (node.py:438);
+* trainers / proxies / idle nodes adopt the model of an aggregating neighbour
+  (aggregator.py:119-123); in SDFL the aggregator role moves to a random neighbour after every
+  round (node.py:648-650,676-686);
+* dead nodes (fault injection / heartbeat eviction) drop out of every train set and stop training.
+
+Model exchange is *not* message passing: rows of co-resident neighbours are read in place by
+the fused reduce kernel; rows owned by other GPUs are moved with RCCL over xGMI — a single
+all-reduce of the local partial sum when every node shares one train set (fully connected, star),
+or one variable-split all-to-all of exactly the rows each peer needs (ring / random graphs).
+With ``encrypt=True`` the rows that leave a GPU are AES-128-ECB encrypted on the device with a
+per-link key and decrypted on arrival (the reference's per-link AES, encrypter.py:109-193).
+"""
+from __future__ import annotations
+
+import hashlib
+import random
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ..models.specs import ModelSpec
+from ..role import Role, default_roles
+from .aggregation import AggregationPlan, build_plan, plan_from_train_sets, run_plan
+from .engine import ShardEngine, make_engine
+
+
+@dataclass
+class RoundReport:
+    round: int
+    seconds: float
+    phase_seconds: Dict[str, float]
+    train_samples: int               # samples processed by local training on this rank
+    test_loss: Optional[torch.Tensor] = None
+    test_accuracy: Optional[torch.Tensor] = None
+    train_loss: Optional[torch.Tensor] = None
+    exchanged_rows: int = 0
+
+
+def partition_nodes(n_nodes: int, world: int) -> List[range]:
+    """Contiguous, balanced blocks of node ids per rank."""
+    base, rem = divmod(n_nodes, world)
+    out, start = [], 0
+    for r in range(world):
+        cnt = base + (1 if r < rem else 0)
+        out.append(range(start, start + cnt))
+        start += cnt
+    return out
+
+
+def link_key(scenario: str, a: int, b: int) -> bytes:
+    """Deterministic 16-byte AES key of the (unordered) rank link a<->b."""
+    lo, hi = (a, b) if a <= b else (b, a)
+    return hashlib.sha256(f"{scenario}|link|{lo}|{hi}".encode()).digest()[:16]
+
+
+class BatchedFederation:
+    def __init__(self, spec: ModelSpec, topology, *, federation: str = "DFL", roles: Optional[Sequence[str]] = None,
+                 device="cpu", engine: str = "auto", batch_size: int = 32, epochs: int = 1, seed: int = 0,
+                 rank: int = 0, world_size: int = 1, process_group=None, encrypt: bool = False,
+                 scenario: str = "scenario", persist_optimizer: bool = False, use_graph: bool = True):
+        self.spec = spec
+        self.adj = np.asarray(topology, dtype=np.float32)
+        self.N = self.adj.shape[0]
+        self.federation = federation.upper()
+        self.roles = list(roles) if roles is not None else default_roles(self.federation, self.N)
+        self.epochs = epochs
+        self.rank, self.world = rank, world_size
+        self.pg = process_group
+        self.encrypt = encrypt
+        self.scenario = scenario
+        self.device = torch.device(device)
+        self.blocks = partition_nodes(self.N, self.world)
+        self.owner = np.zeros(self.N, dtype=np.int64)
+        for r, blk in enumerate(self.blocks):
+            self.owner[list(blk)] = r
+        self.local = self.blocks[rank]
+        self.n_local = len(self.local)
+        self.engine: ShardEngine = make_engine(spec, self.n_local, self.device, impl=engine, batch_size=batch_size,
+                                               seed=seed, persist_optimizer=persist_optimizer,
+                                               **({"use_graph": use_graph} if engine != "eager" else {}))
+        self.alive = np.ones(self.N, dtype=bool)
+        self.weights = np.zeros(self.N, dtype=np.float64)       # training samples per node
+        self.round = 0
+        self.rng = random.Random(seed)                            # shared by all ranks (same seed)
+        self.staging: Optional[torch.Tensor] = None
+        self._plan_cache: Dict[bytes, tuple] = {}
+        self._rk_cache: Dict[tuple, torch.Tensor] = {}
+        self.faults: Dict[int, List[tuple]] = {}                  # round -> [(action, node)]
+        self.reports: List[RoundReport] = []
+
+    # ------------------------------------------------------------------ setup
+    def init_params(self, seed: Optional[int] = None) -> None:
+        self.engine.init_params(seed=seed, identical=True)
+
+    def set_local_data(self, train_x, train_y, val_x=None, val_y=None, test_x=None, test_y=None,
+                       n_train_all: Optional[Sequence[int]] = None) -> None:
+        """Install the data shards of this rank's nodes. ``n_train_all``: training-set size of EVERY
+        node of the scenario (FedAvg weights, node.py:447); default: all equal to the local size."""
+        self.engine.set_data(train_x, train_y, val_x, val_y, test_x, test_y)
+        if n_train_all is None:
+            self.weights[:] = train_x.shape[1]
+        else:
+            self.weights[:] = np.asarray(n_train_all, dtype=np.float64)
+
+    def schedule_fault(self, round_idx: int, action: str, node: int) -> None:
+        """Deterministic churn: ``action`` in {"kill", "revive"} applied at the start of a round."""
+        self.faults.setdefault(round_idx, []).append((action, node))
+
+    # ------------------------------------------------------------------ per-round structure
+    def neighbors(self, i: int) -> List[int]:
+        return [int(j) for j in np.nonzero(self.adj[i])[0] if j != i]
+
+    def train_set(self, i: int) -> List[int]:
+        if not self.alive[i]:
+            return []
+        return sorted([j for j in self.neighbors(i) if self.alive[j]] + [i])
+
+    def _round_structure(self):
+        """(train_sets of aggregating nodes, adopt map of waiting nodes) for the current state."""
+        train_sets: Dict[int, List[int]] = {}
+        adopt: Dict[int, int] = {}
+        for i in range(self.N):
+            if self.alive[i] and Role.aggregates(self.roles[i]):
+                # contributors: live members of the train set that hold a model to contribute
+                # (proxy/idle nodes never add their own model, node.py:492-524)
+                ts = [j for j in self.train_set(i) if self.roles[j] not in (Role.PROXY, Role.IDLE)]
+                train_sets[i] = ts
+        for i in range(self.N):
+            if self.alive[i] and Role.waits(self.roles[i]):
+                aggs = [j for j in self.neighbors(i) if self.alive[j] and j in train_sets]
+                if aggs:
+                    adopt[i] = aggs[0]
+        return train_sets, adopt
+
+    def _structure_key(self) -> bytes:
+        h = hashlib.sha1()
+        h.update(self.alive.tobytes())
+        h.update("|".join(self.roles).encode())
+        return h.digest()
+
+    def _build_exchange(self, train_sets, adopt):
+        """Who needs which remote rows. Returns (send_lists, recv_lists, row_of, plan, mode)."""
+        me = self.rank
+        local_set = set(self.local)
+        lo = self.local.start
+        needed_by: List[set] = [set() for _ in range(self.world)]   # needed_by[r] = nodes rank r must receive
+        for i, ts in train_sets.items():
+            # the result of i is needed on owner(i) and on the owners of nodes adopting it
+            dest_ranks = {int(self.owner[i])} | {int(self.owner[w]) for w, a in adopt.items() if a == i}
+            for r in dest_ranks:
+                for j in ts:
+                    if self.owner[j] != r:
+                        needed_by[r].add(j)
+        # single-group fast path: every destination shares one contributor set -> all-reduce
+        keys = {tuple(ts) for ts in train_sets.values()}
+        if self.world > 1 and len(keys) == 1:
+            contributors = list(next(iter(keys)))
+            dests = sorted(set(train_sets) | set(adopt))
+            tot = float(sum(self.weights[j] for j in contributors))
+            loc_src = [j for j in contributors if j in local_set]
+            loc_dst = [d for d in dests if d in local_set]
+            return ("allreduce", loc_src, [self.weights[j] / tot for j in loc_src], loc_dst)
+        send_lists = [sorted(j for j in needed_by[r] if self.owner[j] == me) if r != me else []
+                      for r in range(self.world)]
+        recv_lists = [sorted(j for j in needed_by[me] if self.owner[j] == r) if r != me else []
+                      for r in range(self.world)]
+        row_of = {j: j - lo for j in self.local}
+        pos = self.n_local
+        for r in range(self.world):
+            for j in recv_lists[r]:
+                row_of[j] = pos
+                pos += 1
+        # plan restricted to destinations on this rank
+        dest_rows = {j: j - lo for j in self.local}
+        ts_local, adopt_local = {}, {}
+        for i, ts in train_sets.items():
+            if i in local_set:
+                ts_local[i] = ts
+        groups: Dict[tuple, List[int]] = {}
+        for i, ts in train_sets.items():
+            dsts = ([i] if i in local_set else []) + [w for w, a in adopt.items() if a == i and w in local_set]
+            if not dsts:
+                continue
+            key = tuple(ts)
+            groups.setdefault(key, []).extend(dest_rows[d] for d in dsts)
+        plan = build_plan([([row_of[j] for j in key], [self.weights[j] for j in key], dsts)
+                           for key, dsts in groups.items()])
+        return ("rows", send_lists, recv_lists, plan, pos - self.n_local)
+
+    # ------------------------------------------------------------------ exchange primitives
+    def _round_keys(self, a: int, b: int) -> torch.Tensor:
+        key = (min(a, b), max(a, b))
+        t = self._rk_cache.get(key)
+        if t is None:
+            from ..utils.aes import expand_key
+            t = torch.tensor(list(expand_key(link_key(self.scenario, a, b))), dtype=torch.uint8, device=self.device)
+            self._rk_cache[key] = t
+        return t
+
+    def _crypt(self, buf: torch.Tensor, peer: int, decrypt: bool) -> torch.Tensor:
+        """AES-128-ECB over a [rows, P] fp32 buffer with the key of link (rank, peer)."""
+        if buf.numel() == 0:
+            return buf
+        raw = buf.view(torch.uint8).reshape(-1)
+        if buf.is_cuda:
+            from ..ops import hip
+            out = torch.empty_like(raw)
+            hip.aes128_ecb(raw, out, self._round_keys(self.rank, peer), decrypt)
+            return out.view(torch.float32).reshape(buf.shape)
+        from ..utils.aes import ecb_host
+        data = ecb_host(link_key(self.scenario, self.rank, peer), raw.numpy().tobytes(), decrypt)
+        return torch.frombuffer(bytearray(data), dtype=torch.float32).reshape(buf.shape)
+
+    def _exchange_rows(self, send_lists, recv_lists, n_recv: int) -> int:
+        """Move the needed parameter rows between ranks into ``self.staging``."""
+        eng = self.engine
+        P = eng.layout.row_stride
+        if self.staging is None or self.staging.shape[0] < max(n_recv, 1):
+            self.staging = torch.zeros(max(n_recv, 1), P, device=self.device)
+        if self.world == 1:
+            return 0
+        lo = self.local.start
+        send_bufs = []
+        for r in range(self.world):
+            if send_lists[r]:
+                idx = torch.tensor([j - lo for j in send_lists[r]], device=self.device)
+                buf = eng.params.index_select(0, idx)
+                if self.encrypt:
+                    buf = self._crypt(buf, r, decrypt=False)
+                send_bufs.append(buf)
+            else:
+                send_bufs.append(torch.zeros(0, P, device=self.device))
+        recv_sizes = [len(l) for l in recv_lists]
+        backend = dist.get_backend(self.pg)
+        if backend == "nccl":
+            send_cat = torch.cat(send_bufs, dim=0) if sum(len(l) for l in send_lists) else torch.zeros(0, P, device=self.device)
+            recv_cat = self.staging[:n_recv] if not self.encrypt else torch.empty(n_recv, P, device=self.device)
+            dist.all_to_all_single(recv_cat, send_cat, output_split_sizes=recv_sizes,
+                                   input_split_sizes=[len(l) for l in send_lists], group=self.pg)
+        else:
+            recv_cat = torch.empty(n_recv, P, device=self.device)
+            ops, off = [], 0
+            for r in range(self.world):
+                if recv_sizes[r]:
+                    ops.append(dist.P2POp(dist.irecv, recv_cat[off:off + recv_sizes[r]], r, group=self.pg))
+                    off += recv_sizes[r]
+                if send_lists[r]:
+                    ops.append(dist.P2POp(dist.isend, send_bufs[r].contiguous(), r, group=self.pg))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+        if self.encrypt:
+            off = 0
+            for r in range(self.world):
+                if recv_sizes[r]:
+                    self.staging[off:off + recv_sizes[r]] = self._crypt(recv_cat[off:off + recv_sizes[r]].contiguous(), r, True)
+                    off += recv_sizes[r]
+        elif recv_cat.data_ptr() != self.staging.data_ptr():
+            self.staging[:n_recv] = recv_cat
+        return n_recv
+
+    # ------------------------------------------------------------------ the round
+    def _apply_faults(self) -> None:
+        for action, node in self.faults.get(self.round, []):
+            self.alive[node] = action != "kill"
+
+    def aggregate(self) -> int:
+        """Exchange + FedAvg for the current membership/roles. Returns #rows received from peers."""
+        eng = self.engine
+        train_sets, adopt = self._round_structure()
+        if not train_sets:
+            return 0
+        key = self._structure_key()
+        cached = self._plan_cache.get(key)
+        if cached is None:
+            cached = self._build_exchange(train_sets, adopt)
+            if cached[0] == "rows":
+                cached = cached[:3] + (cached[3].to(self.device),) + cached[4:]
+            self._plan_cache[key] = cached
+        out = eng.alt_slab()
+        out.copy_(eng.params)            # rows nobody writes (dead / isolated nodes) keep their model
+        if cached[0] == "allreduce":
+            _, loc_src, loc_w, loc_dst = cached
+            lo = self.local.start
+            P = eng.layout.row_stride
+            partial = torch.zeros(1, P, device=self.device)
+            if loc_src:
+                plan = AggregationPlan(torch.tensor([0, len(loc_src)], dtype=torch.int32, device=self.device),
+                                       torch.tensor([j - lo for j in loc_src], dtype=torch.int32, device=self.device),
+                                       torch.tensor(loc_w, dtype=torch.float32, device=self.device),
+                                       torch.tensor([0, 1], dtype=torch.int32, device=self.device),
+                                       torch.tensor([0], dtype=torch.int32, device=self.device), 1)
+                run_plan(eng.params, None, partial, plan)
+            if self.encrypt:
+                # all-reduce has no per-link ciphertext form: fall back to an encrypted all-gather
+                rows = [torch.empty_like(partial) for _ in range(self.world)]
+                enc = [self._crypt(partial, r, False) if r != self.rank else partial for r in range(self.world)]
+                outs = [torch.empty_like(partial) for _ in range(self.world)]
+                dist.all_to_all(outs, enc, group=self.pg) if dist.get_backend(self.pg) == "nccl" else \
+                    self._gloo_all_to_all(outs, enc)
+                partial = sum(self._crypt(o, r, True) if r != self.rank else o for r, o in enumerate(outs))
+            else:
+                dist.all_reduce(partial, group=self.pg)
+            if loc_dst:
+                idx = torch.tensor([d - lo for d in loc_dst], device=self.device)
+                out[idx] = partial.expand(len(loc_dst), -1)
+            eng.swap_slabs()
+            return self.world - 1
+        _, send_lists, recv_lists, plan, n_recv = cached
+        got = self._exchange_rows(send_lists, recv_lists, n_recv)
+        run_plan(eng.params, self.staging, out, plan)
+        eng.swap_slabs()
+        return got
+
+    def _gloo_all_to_all(self, outs, ins) -> None:
+        ops = []
+        for r in range(self.world):
+            if r == self.rank:
+                outs[r].copy_(ins[r])
+                continue
+            ops.append(dist.P2POp(dist.irecv, outs[r], r, group=self.pg))
+            ops.append(dist.P2POp(dist.isend, ins[r].contiguous(), r, group=self.pg))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+    def _transfer_leadership(self) -> None:
+        """SDFL: the aggregator hands its role to a random live neighbour (node.py:676-686)."""
+        for i in range(self.N):
+            if self.roles[i] == Role.AGGREGATOR and self.alive[i]:
+                cands = [j for j in self.neighbors(i) if self.alive[j]]
+                if cands:
+                    j = self.rng.choice(cands)
+                    self.roles[i] = Role.TRAINER
+                    self.roles[j] = Role.AGGREGATOR
+                break
+
+    def run_round(self, evaluate: bool = True, sync_timing: bool = True) -> RoundReport:
+        eng = self.engine
+        t0 = time.perf_counter()
+        phases: Dict[str, float] = {}
+        self._apply_faults()
+
+        def tick(name, t_prev):
+            if sync_timing:
+                eng.synchronize()
+            now = time.perf_counter()
+            phases[name] = now - t_prev
+            return now
+
+        t = t0
+        test = None
+        if evaluate:                      # evaluation happens BEFORE training (node.py:433-435)
+            test = eng.evaluate()
+            t = tick("evaluate", t)
+        lo = self.local.start
+        active = torch.tensor([bool(self.alive[i]) and Role.trains(self.roles[i]) for i in self.local])
+        fit = eng.fit(self.epochs, active=active)
+        t = tick("train", t)
+        got = self.aggregate()
+        t = tick("aggregate", t)
+        if self.federation == "SDFL":
+            self._transfer_leadership()
+        n_train = eng.train_x.shape[1]
+        rep = RoundReport(self.round, time.perf_counter() - t0, phases,
+                          int(active.sum().item()) * n_train * self.epochs,
+                          None if test is None else test["loss"], None if test is None else test["accuracy"],
+                          fit.get("Train", {}).get("loss") if fit else None, got)
+        self.reports.append(rep)
+        self.round += 1
+        return rep
+
+    def run(self, rounds: int, evaluate: bool = True) -> List[RoundReport]:
+        out = [self.run_round(evaluate=evaluate) for _ in range(rounds)]
+        if evaluate:                      # one more evaluation at the very end (node.py:663)
+            self.final_test = self.engine.evaluate()
+        return out

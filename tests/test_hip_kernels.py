@@ -1,0 +1,281 @@
+"""Numerics of every gfx950 kernel against a plain PyTorch fp32 reference of the same op.
+
+Matrix-core kernels round their operands to bf16 (fp32 accumulate), so they are compared with
+a bf16-appropriate tolerance; VALU kernels (conv1 forward, CE, optimizers, FedAvg, AES) must
+match to fp32 round-off / exactly.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def hip():
+    from p2pfl_amd.ops import hip as h
+    h.load()
+    return h
+
+
+def rel_err(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp(min=1e-12)).item()
+
+
+def slab_view(K, shape, pad=64):
+    """A [K, *shape] view with a slab-like (larger, aligned) client stride."""
+    n = 1
+    for s in shape:
+        n *= s
+    stride = -(-n // 64) * 64 + pad
+    slab = torch.randn(K, stride, device=DEV)
+    return slab[:, :n].unflatten(1, shape)
+
+
+def route(g, code, P):
+    """Dense pre-pool gradient from pooled gradient + arg-max codes. g/code [..., C, P*P]."""
+    lead = g.shape[:-1]
+    gg = g.reshape(*lead, P, P)
+    cc = code.reshape(*lead, P, P)
+    out = torch.zeros(*lead, P, 2, P, 2, device=g.device)
+    for q in range(4):
+        out[..., :, q >> 1, :, q & 1] = torch.where(cc == q, gg, torch.zeros_like(gg))
+    return out.reshape(*lead, 2 * P, 2 * P)
+
+
+@pytest.mark.parametrize("K,B,In,Out,relu", [(3, 32, 784, 256, True), (2, 20, 128, 10, False),
+                                             (2, 32, 3136, 2048, True), (1, 5, 36, 7, False)])
+def test_linear_fwd(K, B, In, Out, relu):
+    h = hip()
+    x = torch.randn(K, B, In, device=DEV)
+    w = slab_view(K, (Out, In)) * 0.05
+    b = slab_view(K, (Out,))
+    y = torch.empty(K, B, Out, device=DEV)
+    h.linear_fwd(x, w, b, y, relu)
+    ref = torch.baddbmm(b.unsqueeze(1), x, w.transpose(1, 2))
+    if relu:
+        ref = ref.relu()
+    assert rel_err(y, ref) < 2e-2
+
+
+@pytest.mark.parametrize("K,B,In,Out,mask", [(3, 32, 256, 128, True), (2, 32, 2048, 10, True),
+                                             (2, 28, 3136, 2048, False), (1, 7, 50, 6, False)])
+def test_linear_dgrad(K, B, In, Out, mask):
+    h = hip()
+    dy = torch.randn(K, B, Out, device=DEV)
+    w = slab_view(K, (Out, In)) * 0.05
+    act = torch.randn(K, B, In, device=DEV).relu() if mask else None
+    dx = torch.empty(K, B, In, device=DEV)
+    h.linear_dgrad(dy, w, act, dx)
+    ref = torch.bmm(dy, w)
+    if mask:
+        ref = ref * (act > 0)
+    assert rel_err(dx, ref) < 2e-2
+
+
+@pytest.mark.parametrize("K,B,In,Out", [(3, 32, 784, 256), (2, 32, 2048, 10), (2, 17, 3136, 70), (1, 40, 33, 5)])
+def test_linear_wgrad(K, B, In, Out):
+    h = hip()
+    dy = torch.randn(K, B, Out, device=DEV)
+    x = torch.randn(K, B, In, device=DEV)
+    dw = slab_view(K, (Out, In))
+    db = slab_view(K, (Out,))
+    h.linear_wgrad(dy, x, dw, db)
+    assert rel_err(dw, torch.bmm(dy.transpose(1, 2), x)) < 2e-2
+    assert rel_err(db, dy.sum(1)) < 2e-2
+
+
+@pytest.mark.parametrize("ks", [5, 7])
+def test_conv1_fwd(ks):
+    h = hip()
+    K, n, B, Fm = 3, 40, 32, 32
+    data = torch.rand(K, n, 784, device=DEV)
+    sidx = torch.stack([torch.randperm(n, device=DEV)[:B] for _ in range(K)]).int()
+    w = slab_view(K, (Fm, ks * ks)) * 0.2
+    b = slab_view(K, (Fm,)) * 0.1
+    a1 = torch.empty(K, B, Fm, 196, device=DEV)
+    code = torch.empty(K, B, Fm, 196, dtype=torch.uint8, device=DEV)
+    h.conv1_fwd(data, sidx, w, b, a1, code, ks)
+    for k in range(K):
+        xb = data[k][sidx[k].long()].view(B, 1, 28, 28)
+        pre = F.conv2d(xb, w[k].reshape(Fm, 1, ks, ks), b[k], padding=ks // 2)
+        ref = F.max_pool2d(pre.relu(), 2, 2).reshape(B, Fm, 196)
+        assert torch.allclose(a1[k], ref, atol=1e-4, rtol=1e-4)
+        # the code must point at the arg-max (or 4 when the window is <= 0)
+        win = pre.reshape(B, Fm, 14, 2, 14, 2).permute(0, 1, 2, 4, 3, 5).reshape(B, Fm, 196, 4)
+        c = code[k].long()
+        pos = c < 4
+        picked = torch.gather(win, 3, c.clamp(max=3).unsqueeze(-1)).squeeze(-1)
+        assert torch.allclose(picked[pos], ref[pos], atol=1e-4, rtol=1e-4)
+        assert (ref[~pos] == 0).all()
+
+
+@pytest.mark.parametrize("ks", [5, 7])
+def test_conv1_wgrad(ks):
+    h = hip()
+    K, n, B, Fm = 2, 40, 32, 32
+    data = torch.rand(K, n, 784, device=DEV)
+    sidx = torch.stack([torch.randperm(n, device=DEV)[:B] for _ in range(K)]).int()
+    g = torch.randn(K, B, Fm, 196, device=DEV)
+    code = torch.randint(0, 5, (K, B, Fm, 196), device=DEV).to(torch.uint8)
+    dw = slab_view(K, (Fm, ks * ks))
+    db = slab_view(K, (Fm,))
+    h.conv1_wgrad(g, code, data, sidx, dw, db, ks)
+    dpre = route(g, code, 14)
+    for k in range(K):
+        xb = data[k][sidx[k].long()].view(B, 1, 28, 28)
+        ref = torch.nn.grad.conv2d_weight(xb, (Fm, 1, ks, ks), dpre[k], padding=ks // 2).reshape(Fm, ks * ks)
+        assert rel_err(dw[k], ref) < 2e-2
+        assert rel_err(db[k], dpre[k].sum(dim=(0, 2, 3))) < 2e-2
+
+
+@pytest.mark.parametrize("ks,B", [(5, 32), (3, 32), (5, 9)])
+def test_conv2_fwd(ks, B):
+    h = hip()
+    K, Cin, Cout = 2, 32, 64
+    a1 = torch.randn(K, B, Cin, 196, device=DEV).relu()
+    w = slab_view(K, (Cout, Cin * ks * ks)) * 0.05
+    b = slab_view(K, (Cout,)) * 0.1
+    a2 = torch.empty(K, B, Cout, 49, device=DEV)
+    code = torch.empty(K, B, Cout, 49, dtype=torch.uint8, device=DEV)
+    h.conv2_fwd(a1, w, b, a2, code, ks)
+    for k in range(K):
+        pre = F.conv2d(a1[k].view(B, Cin, 14, 14), w[k].reshape(Cout, Cin, ks, ks), b[k], padding=ks // 2)
+        ref = F.max_pool2d(pre.relu(), 2, 2).reshape(B, Cout, 49)
+        assert rel_err(a2[k], ref) < 2e-2
+        assert ((a2[k] == 0) == (code[k] == 4)).all()
+
+
+@pytest.mark.parametrize("ks,B", [(5, 32), (3, 32), (5, 9)])
+def test_conv2_wgrad_dgrad(ks, B):
+    h = hip()
+    K, Cin, Cout = 2, 32, 64
+    a1 = torch.randn(K, B, Cin, 196, device=DEV).relu()
+    w = slab_view(K, (Cout, Cin * ks * ks)) * 0.05
+    g = torch.randn(K, B, Cout, 49, device=DEV)
+    code = torch.randint(0, 5, (K, B, Cout, 49), device=DEV).to(torch.uint8)
+    dw = slab_view(K, (Cout, Cin * ks * ks))
+    db = slab_view(K, (Cout,))
+    da1 = torch.empty(K, B, Cin, 196, device=DEV)
+    h.conv2_wgrad(g, code, a1, dw, db, ks)
+    h.conv2_dgrad(g, code, w, da1, ks)
+    dpre = route(g, code, 7)   # [K,B,Cout,14,14]
+    for k in range(K):
+        x = a1[k].view(B, Cin, 14, 14)
+        wk = w[k].reshape(Cout, Cin, ks, ks)
+        ref_w = torch.nn.grad.conv2d_weight(x, wk.shape, dpre[k], padding=ks // 2).reshape(Cout, -1)
+        ref_x = torch.nn.grad.conv2d_input(x.shape, wk, dpre[k], padding=ks // 2).reshape(B, Cin, 196)
+        assert rel_err(dw[k], ref_w) < 2e-2
+        assert rel_err(db[k], dpre[k].sum(dim=(0, 2, 3))) < 2e-2
+        assert rel_err(da1[k], ref_x) < 2e-2
+
+
+@pytest.mark.parametrize("C,B,nv", [(10, 32, 32), (62, 32, 28), (10, 100, 77)])
+def test_softmax_ce(C, B, nv):
+    h = hip()
+    K, n = 4, 200
+    logits = torch.randn(K, B, C, device=DEV) * 3
+    labels = torch.randint(0, C, (K, n), device=DEV).int()
+    sidx = torch.stack([torch.randperm(n, device=DEV)[:B] for _ in range(K)]).int()
+    dl = torch.empty_like(logits)
+    loss = torch.zeros(K, device=DEV)
+    corr = torch.zeros(K, dtype=torch.int32, device=DEV)
+    cnt = torch.zeros(K, dtype=torch.int32, device=DEV)
+    cm = torch.zeros(K, C, C, dtype=torch.int32, device=DEV)
+    nvt = torch.full((K,), nv, dtype=torch.int32, device=DEV)
+    h.softmax_ce(logits, labels, sidx, dl, loss, corr, cnt, cm, nvt)
+    for k in range(K):
+        y = labels[k][sidx[k].long()].long()[:nv]
+        z = logits[k, :nv].clone().requires_grad_(True)
+        ref = F.cross_entropy(z, y, reduction="sum")
+        (ref / nv).backward()
+        assert torch.allclose(loss[k], ref.detach(), rtol=1e-4, atol=1e-4)
+        assert torch.allclose(dl[k, :nv], z.grad, atol=1e-6, rtol=1e-4)
+        assert (dl[k, nv:] == 0).all()
+        pred = logits[k, :nv].argmax(1)
+        assert corr[k].item() == (pred == y).sum().item()
+        assert cnt[k].item() == nv
+        ref_cm = torch.zeros(C, C, dtype=torch.int32, device=DEV)
+        ref_cm.view(-1).index_add_(0, y * C + pred, torch.ones(nv, dtype=torch.int32, device=DEV))
+        assert (cm[k] == ref_cm).all()
+
+
+def test_adam_and_sgd_trajectories():
+    h = hip()
+    K, n = 3, 1000
+    stride = 1024
+    p = torch.randn(K, stride, device=DEV)[:, :n]
+    m = torch.zeros(K, stride, device=DEV)[:, :n]
+    v = torch.zeros(K, stride, device=DEV)[:, :n]
+    ref_p = [torch.nn.Parameter(p[k].clone()) for k in range(K)]
+    opt = torch.optim.Adam(ref_p, lr=1e-3)
+    bc = torch.zeros(2, device=DEV)
+    for t in range(1, 8):
+        g = torch.randn(K, stride, device=DEV)[:, :n]
+        if t % 2:
+            h.adam_step(p, g, m, v, lr=1e-3, t=t)
+        else:   # run-time bias corrections (graph-replay path)
+            bc.copy_(torch.tensor([1 / (1 - 0.9 ** t), 1 / (1 - 0.999 ** t) ** 0.5]))
+            h.adam_step(p, g, m, v, lr=1e-3, t=1, bc=bc)
+        for k in range(K):
+            ref_p[k].grad = g[k].clone()
+        opt.step()
+    for k in range(K):
+        assert torch.allclose(p[k], ref_p[k].detach(), atol=1e-6, rtol=1e-5)
+
+    p = torch.randn(K, stride, device=DEV)[:, :n]
+    buf = torch.zeros(K, stride, device=DEV)[:, :n]
+    ref_p = [torch.nn.Parameter(p[k].clone()) for k in range(K)]
+    opt = torch.optim.SGD(ref_p, lr=1e-2, momentum=0.9)
+    for t in range(5):
+        g = torch.randn(K, stride, device=DEV)[:, :n]
+        h.sgdm_step(p, g, buf, lr=1e-2, momentum=0.9)
+        for k in range(K):
+            ref_p[k].grad = g[k].clone()
+        opt.step()
+    for k in range(K):
+        assert torch.allclose(p[k], ref_p[k].detach(), atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("n_local,n_remote,P", [(8, 0, 4096), (5, 3, 1000 * 4), (1000, 0, 256)])
+def test_fedavg_groups(n_local, n_remote, P):
+    from p2pfl_amd.runtime.aggregation import build_plan, fedavg_reference, run_plan
+    local = torch.randn(n_local, P, device=DEV)
+    remote = torch.randn(n_remote, P, device=DEV) if n_remote else None
+    pool_n = n_local + n_remote
+    gen = torch.Generator().manual_seed(0)
+    groups = []
+    # star-like fan-in over everything -> all rows; then a few random subsets
+    groups.append((list(range(pool_n)), torch.randint(1, 600, (pool_n,), generator=gen).tolist(), [0]))
+    for d in range(1, min(n_local, 6)):
+        k = int(torch.randint(1, min(pool_n, 7) + 1, (1,), generator=gen))
+        srcs = torch.randperm(pool_n, generator=gen)[:k].tolist()
+        groups.append((srcs, torch.randint(1, 600, (k,), generator=gen).tolist(), [d]))
+    plan = build_plan(groups)
+    out = torch.zeros(n_local, P, device=DEV)
+    ref = torch.zeros(n_local, P, device=DEV)
+    run_plan(local, remote, out, plan)
+    fedavg_reference(local, remote, ref, plan)
+    assert torch.allclose(out, ref, atol=1e-5, rtol=1e-5)
+
+
+def test_aes128_ecb_known_answer_and_roundtrip():
+    h = hip()
+    from p2pfl_amd.utils.aes import expand_key, ecb_host
+    key = bytes(range(16))
+    pt = bytes.fromhex("00112233445566778899aabbccddeeff")
+    expect = bytes.fromhex("69c4e0d86a7b0430d8cdb78070b4c55a")   # FIPS-197 C.1
+    rk = torch.tensor(list(expand_key(key)), dtype=torch.uint8, device=DEV)
+    src = torch.tensor(list(pt) * 64, dtype=torch.uint8, device=DEV)
+    enc = torch.empty_like(src)
+    h.aes128_ecb(src, enc, rk, decrypt=False)
+    assert bytes(enc[:16].cpu().tolist()) == expect
+    assert bytes(enc.cpu().tolist()) == ecb_host(key, bytes(src.cpu().tolist()), decrypt=False)
+    big = torch.randint(0, 256, (1 << 20,), dtype=torch.uint8, device=DEV)
+    e2 = torch.empty_like(big)
+    d2 = torch.empty_like(big)
+    h.aes128_ecb(big, e2, rk, decrypt=False)
+    h.aes128_ecb(e2, d2, rk, decrypt=True)
+    assert (d2 == big).all()
+    assert bytes(e2[:4096].cpu().tolist()) == ecb_host(key, bytes(big[:4096].cpu().tolist()), decrypt=False)

@@ -33,7 +33,10 @@ __device__ __forceinline__ int mfma_row(int reg, int lane) {
     return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
 }
 
-template <int ROWS, int NT, class Loader>
+// PERM4 (ROWS == 128 only): LDS row rho holds global row 4*(rho & 31) + (rho >> 5). With four
+// 32-column MFMA tiles per wave this puts output columns 4r..4r+3 into the four accumulators of
+// lane r, so an epilogue can move float4 (16 B) per lane along the contiguous output dimension.
+template <int ROWS, int NT, class Loader, bool PERM4 = false>
 struct TileStager {
     static constexpr int CHUNKS = ROWS * 4;                    // 16-B (8 x bf16) chunks per tile
     static constexpr int PER_THREAD = (CHUNKS + NT - 1) / NT;  // chunks each thread moves
@@ -49,6 +52,7 @@ struct TileStager {
             int c = threadIdx.x + i * NT;
             if (CHUNKS % NT == 0 || c < CHUNKS) {
                 int row, k8; decode(c, row, k8);
+                if (PERM4) row = 4 * (row & 31) + (row >> 5);
                 ld.load8(row0 + row, k0 + k8 * 8, v[i]);
             }
         }
@@ -73,7 +77,9 @@ struct GemmSmem {
 
 // Runs one BM x BN block tile over k in [k_begin, k_end) (k_begin % 32 == 0; loaders
 // zero-fill past their own K extent). All threads of the block must call it.
-template <int BM, int BN, int WR, int WC, class AL, class BL, class EPI>
+// N4 = true (needs BN == 128, WC == 1): B is staged with the PERM4 row permutation and the epilogue
+// is called as  epi.store4(float4 v, int m, int n)  with v = C[m][n .. n+3], n % 4 == 0.
+template <int BM, int BN, int WR, int WC, class AL, class BL, class EPI, bool N4 = false>
 __device__ __forceinline__ void gemm_block_tile(GemmSmem<BM, BN>& sm, const AL& al, const BL& bl,
                                                 const EPI& epi, int m0, int n0, int k_begin,
                                                 int k_end) {
@@ -96,7 +102,8 @@ __device__ __forceinline__ void gemm_block_tile(GemmSmem<BM, BN>& sm, const AL& 
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     TileStager<BM, NT, AL> sa;
-    TileStager<BN, NT, BL> sb;
+    TileStager<BN, NT, BL, N4> sb;
+    static_assert(!N4 || (BN == 128 && WC == 1), "N4 epilogue needs one 128-column wave tile");
 
     sa.load(al, m0, k_begin);
     sb.load(bl, n0, k_begin);
@@ -136,11 +143,20 @@ __device__ __forceinline__ void gemm_block_tile(GemmSmem<BM, BN>& sm, const AL& 
         cur ^= 1;
     }
 
+    if constexpr (N4) {
 #pragma unroll
-    for (int i = 0; i < RM; ++i)
+        for (int i = 0; i < RM; ++i)
 #pragma unroll
-        for (int j = 0; j < RN; ++j)
-            epi(acc[i][j], m0 + wr * TM + i * 32, n0 + wc * TN + j * 32);
+            for (int e = 0; e < 16; ++e)
+                epi.store4(make_float4(acc[i][0][e], acc[i][1][e], acc[i][2][e], acc[i][3][e]),
+                           m0 + wr * TM + i * 32 + mfma_row(e, lane), n0 + 4 * r);
+    } else {
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j)
+                epi(acc[i][j], m0 + wr * TM + i * 32, n0 + wc * TN + j * 32);
+    }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -112,6 +112,19 @@ struct LoadXTOnes {
 
 struct EpiWgradStore {
     float* dw; float* db; int M, N;  // M = Out, N = In (column N = bias)
+    __device__ __forceinline__ void store4(float4 g, int m, int n) const {
+        if (m >= M || n > N) return;
+        if (n + 3 < N && (N & 3) == 0) {
+            *reinterpret_cast<float4*>(dw + (size_t)m * N + n) = g;
+        } else {
+            const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (n + j < N) dw[(size_t)m * N + n + j] = gv[j];
+                else if (n + j == N) db[m] = gv[j];
+            }
+        }
+    }
     __device__ __forceinline__ void operator()(const f32x16& acc, int m0, int n0) const {
         const int lane = threadIdx.x & 63;
         const int n = n0 + (lane & 31);
@@ -134,12 +147,104 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(WgradArgs a) {
     LoadColMajorK al{a.dy + c * a.dy_cs, a.Out, a.B, a.Out};
     LoadXTOnes bl{a.x + c * a.x_cs, a.In, a.B};
     EpiWgradStore epi{a.dw + c * a.dw_cs, a.db + c * a.db_cs, a.Out, a.In};
-    gemm_block_tile<128, 128, 2, 2>(sm, al, bl, epi, blockIdx.y * 128, blockIdx.x * 128, 0, a.B);
+    gemm_block_tile<128, 128, 4, 1, LoadColMajorK, LoadXTOnes, EpiWgradStore, true>(
+        sm, al, bl, epi, blockIdx.y * 128, blockIdx.x * 128, 0, a.B);
+}
+
+// ---------------------------------------------------------------------------------------
+// Weight gradient fused with the Adam update. For the big layers (MNIST-CNN l1: 6.4 M weights
+// per client) the gradient tile never leaves the accumulators: the epilogue reads p/m/v,
+// applies Adam and writes p/m/v back, so the 25.7 MB/client gradient is neither written nor
+// re-read (the un-fused pair moves 9 words per weight, this kernel 6).
+// ---------------------------------------------------------------------------------------
+struct AdamHyper {
+    float lr, beta1, beta2, eps, weight_decay, inv_bc1, inv_sqrt_bc2;
+    const float* bc;   // optional device {inv_bc1, inv_sqrt_bc2}
+};
+
+struct EpiWgradAdam {
+    float* w; float* mw; float* vw;     // [M][N] weight, first and second moment
+    float* b; float* mb; float* vb;     // [M] bias and its moments (column N of the product)
+    int M, N;
+    float step, beta1, beta2, eps, wd, isb2;
+    __device__ __forceinline__ void upd(float* p, float* m, float* v, float g) const {
+        const float pv = *p;
+        g += wd * pv;
+        const float mv = beta1 * (*m) + (1.f - beta1) * g;
+        const float vv = beta2 * (*v) + (1.f - beta2) * g * g;
+        *m = mv; *v = vv;
+        *p = pv - step * (mv / (sqrtf(vv) * isb2 + eps));
+    }
+    __device__ __forceinline__ void store4(float4 g, int m, int n) const {
+        if (m >= M || n > N) return;
+        if (n + 3 < N && (N & 3) == 0) {
+            const size_t o = (size_t)m * N + n;
+            float4 pv = *reinterpret_cast<const float4*>(w + o);
+            float4 mv = *reinterpret_cast<const float4*>(mw + o);
+            float4 vv = *reinterpret_cast<const float4*>(vw + o);
+            float* pp = &pv.x; float* mm = &mv.x; float* vq = &vv.x; const float* gg = &g.x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float gr = gg[j] + wd * pp[j];
+                mm[j] = beta1 * mm[j] + (1.f - beta1) * gr;
+                vq[j] = beta2 * vq[j] + (1.f - beta2) * gr * gr;
+                pp[j] -= step * (mm[j] / (sqrtf(vq[j]) * isb2 + eps));
+            }
+            *reinterpret_cast<float4*>(w + o) = pv;
+            *reinterpret_cast<float4*>(mw + o) = mv;
+            *reinterpret_cast<float4*>(vw + o) = vv;
+        } else {
+            const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (n + j < N) { const size_t o = (size_t)m * N + n + j; upd(w + o, mw + o, vw + o, gv[j]); }
+                else if (n + j == N) upd(b + m, mb + m, vb + m, gv[j]);
+            }
+        }
+    }
+};
+
+struct WgradAdamArgs {
+    const float* dy; long dy_cs;
+    const float* x;  long x_cs;
+    float* w; float* mw; float* vw; long w_cs;   // slab views sharing one row stride
+    float* b; float* mb; float* vb; long b_cs;
+    int B, In, Out;
+    AdamHyper h;
+};
+
+__global__ __launch_bounds__(256) void linear_wgrad_adam_kernel(WgradAdamArgs a) {
+    __shared__ GemmSmem<128, 128> sm;
+    const int c = blockIdx.z;
+    LoadColMajorK al{a.dy + c * a.dy_cs, a.Out, a.B, a.Out};
+    LoadXTOnes bl{a.x + c * a.x_cs, a.In, a.B};
+    const float ib1 = a.h.bc ? a.h.bc[0] : a.h.inv_bc1;
+    const float isb2 = a.h.bc ? a.h.bc[1] : a.h.inv_sqrt_bc2;
+    const long wo = c * a.w_cs, bo = c * a.b_cs;
+    EpiWgradAdam epi{a.w + wo, a.mw + wo, a.vw + wo, a.b + bo, a.mb + bo, a.vb + bo, a.Out, a.In,
+                     a.h.lr * ib1, a.h.beta1, a.h.beta2, a.h.eps, a.h.weight_decay, isb2};
+    gemm_block_tile<128, 128, 4, 1, LoadColMajorK, LoadXTOnes, EpiWgradAdam, true>(
+        sm, al, bl, epi, blockIdx.y * 128, blockIdx.x * 128, 0, a.B);
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace
+
+P2PFL_API int p2pfl_linear_wgrad_adam(const float* dy, long dy_cs, const float* x, long x_cs, float* w,
+                                      float* mw, float* vw, long w_cs, float* b, float* mb, float* vb,
+                                      long b_cs, int K, int B, int In, int Out, float lr, float beta1,
+                                      float beta2, float eps, float weight_decay, int t, const float* bc,
+                                      hipStream_t stream) {
+    if (K <= 0 || B <= 0 || In <= 0 || Out <= 0 || t <= 0) return -1;
+    const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
+    WgradAdamArgs a{dy, dy_cs, x, x_cs, w, mw, vw, w_cs, b, mb, vb, b_cs, B, In, Out,
+                    AdamHyper{lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
+                              (float)(1.0 / sqrt(bc2)), bc}};
+    dim3 grid(cdiv(In + 1, 128), cdiv(Out, 128), K);
+    hipLaunchKernelGGL(linear_wgrad_adam_kernel, grid, dim3(256), 0, stream, a);
+    P2PFL_RETURN_LAST_ERROR();
+}
 
 P2PFL_API int p2pfl_linear_fwd(const float* x, long x_cs, const float* w, long w_cs, const float* b,
                                long b_cs, float* y, long y_cs, int K, int B, int In, int Out,

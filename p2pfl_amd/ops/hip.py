@@ -53,6 +53,7 @@ class _Sig:
     p2pfl_linear_fwd = [P, L, P, L, P, L, P, L, I, I, I, I, I, P]
     p2pfl_linear_dgrad = [P, L, P, L, P, L, P, L, I, I, I, I, P]
     p2pfl_linear_wgrad = [P, L, P, L, P, L, P, L, I, I, I, I, P]
+    p2pfl_linear_wgrad_adam = [P, L, P, L, P, P, P, L, P, P, P, L, I, I, I, I, F, F, F, F, F, I, P, P]
     p2pfl_conv1_fwd = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, P]
     p2pfl_conv1_wgrad = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, P]
     p2pfl_conv2_fwd = [P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, P]
@@ -124,6 +125,21 @@ def linear_wgrad(dy, x, dw, db) -> None:
     assert dw.shape == (K, Out, In) and db.shape == (K, Out)
     (dp, ds), (xp, xs), (wp, ws), (bp, bs) = _pc(dy), _pc(x), _pc(dw), _pc(db)
     _chk(load().p2pfl_linear_wgrad(dp, ds, xp, xs, wp, ws, bp, bs, K, B, In, Out, _stream()), "linear_wgrad")
+
+
+def linear_wgrad_adam(dy, x, w, mw, vw, b, mb, vb, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
+                      t: int, bc=None) -> None:
+    """Fused ``dw = dy.T @ x`` + Adam update of (w, b) and their moments; the gradient is never
+    written to memory. w/mw/vw are [K,Out,In] slab views with one common row stride, b/mb/vb [K,Out]."""
+    K, B, Out = dy.shape
+    In = x.shape[2]
+    assert w.shape == (K, Out, In) and b.shape == (K, Out)
+    assert w.stride(0) == mw.stride(0) == vw.stride(0) and b.stride(0) == mb.stride(0) == vb.stride(0)
+    (dp, ds), (xp, xs) = _pc(dy), _pc(x)
+    _chk(load().p2pfl_linear_wgrad_adam(dp, ds, xp, xs, _t(w).data_ptr(), _t(mw).data_ptr(), _t(vw).data_ptr(),
+                                        w.stride(0), _t(b).data_ptr(), _t(mb).data_ptr(), _t(vb).data_ptr(),
+                                        b.stride(0), K, B, In, Out, lr, beta1, beta2, eps, weight_decay, t,
+                                        None if bc is None else _t(bc).data_ptr(), _stream()), "linear_wgrad_adam")
 
 
 # ----------------------------------------------------------------------------- conv

@@ -231,7 +231,7 @@ class EagerEngine(ShardEngine):
 class HipEngine(ShardEngine):
     """Client-batched gfx950 kernels + hipGraph replay (see module docstring)."""
 
-    def __init__(self, *a, use_graph: bool = True, **kw):
+    def __init__(self, *a, use_graph: bool = True, fuse_optimizer: bool = True, **kw):
         super().__init__(*a, **kw)
         if self.device.type != "cuda":
             raise RuntimeError("HipEngine needs a GPU device")
@@ -261,6 +261,24 @@ class HipEngine(ShardEngine):
         self.karange = torch.arange(K, device=dev).unsqueeze(1)
         self._nv_cache: Dict[int, torch.Tensor] = {}
         self._tail_cache: Dict[tuple, torch.Tensor] = {}
+        # big linear layers: weight gradient fused with the Adam update (gradient never hits HBM)
+        self._fused = set()
+        self._adam_ranges = [(0, L.row_stride)]
+        if o.kind == "adam" and fuse_optimizer:
+            cut = []
+            for i, l in enumerate(self.spec.layers):
+                ws, bs = L.by_name[l.weight], L.by_name[l.bias]
+                if l.kind == "linear" and ws.numel >= (1 << 20) and bs.offset == ws.offset + -(-ws.numel // 64) * 64:
+                    self._fused.add(i)
+                    cut.append((ws.offset, bs.offset + -(-bs.numel // 64) * 64))
+            ranges, pos = [], 0
+            for a, b in sorted(cut):
+                if a > pos:
+                    ranges.append((pos, a))
+                pos = b
+            if pos < L.row_stride:
+                ranges.append((pos, L.row_stride))
+            self._adam_ranges = ranges
         self._graphs: Dict[tuple, tuple] = {}
         self._perm_buf = None
         self._bc_buf = None
@@ -307,8 +325,9 @@ class HipEngine(ShardEngine):
         hip.softmax_ce(x, labels, sidx, self.dact[-1] if train else None, st.loss_sum, st.correct, st.count,
                        st.confusion, n_valid)
 
-    def _backward(self, data, sidx) -> None:
+    def _backward(self, data, sidx, step_index: int = 1) -> None:
         hip, layers = self.hip, self.spec.layers
+        o = self.spec.optim
         dy = self.dact[-1]
         for i in range(len(layers) - 1, -1, -1):
             l = layers[i]
@@ -319,13 +338,25 @@ class HipEngine(ShardEngine):
                     xin = self.xin if sidx is not None else data[:, :self.B]
                 else:
                     xin = self.act[i - 1].flatten(2) if self.act[i - 1].dim() > 3 else self.act[i - 1]
-                hip.linear_wgrad(dy, xin, gW, gb)
-                if i > 0:
+                dy_next = None
+                if i > 0:   # data gradient first: it needs the weights BEFORE the fused update below
                     prev = layers[i - 1]
                     mask = self.act[i - 1] if (prev.kind == "linear" and prev.relu) else None
                     dx = self.dact[i - 1].flatten(2) if self.dact[i - 1].dim() > 3 else self.dact[i - 1]
                     hip.linear_dgrad(dy, W, mask, dx)
-                    dy = self.dact[i - 1]
+                    dy_next = self.dact[i - 1]
+                if i in self._fused:
+                    Wb = self._w(self.params, l)
+                    Mb = self._w(self.m, l)
+                    Vb = self._w(self.v, l)
+                    hip.linear_wgrad_adam(dy, xin, Wb[0], Mb[0], Vb[0], Wb[1], Mb[1], Vb[1], lr=o.lr,
+                                          beta1=o.beta1, beta2=o.beta2, eps=o.eps, weight_decay=o.weight_decay,
+                                          t=step_index,
+                                          bc=self._bc_buf[step_index - 1] if self._bc_buf is not None else None)
+                else:
+                    hip.linear_wgrad(dy, xin, gW, gb)
+                if dy_next is not None:
+                    dy = dy_next
             elif l.kind == "conv2pool":
                 hip.conv2_wgrad(dy, self.code[i], self.act[i - 1], gW, gb, l.ksize)
                 hip.conv2_dgrad(dy, self.code[i], W, self.dact[i - 1], l.ksize)
@@ -336,9 +367,11 @@ class HipEngine(ShardEngine):
     def _optim_step(self, step_index: int) -> None:
         o = self.spec.optim
         if o.kind == "adam":
-            self.hip.adam_step(self.params, self.grads, self.m, self.v, lr=o.lr, beta1=o.beta1, beta2=o.beta2,
-                               eps=o.eps, weight_decay=o.weight_decay, t=step_index,
-                               bc=self._bc_buf[step_index - 1] if self._bc_buf is not None else None)
+            for a, b in self._adam_ranges:   # everything the fused wgrad+Adam kernels do not own
+                self.hip.adam_step(self.params[:, a:b], self.grads[:, a:b], self.m[:, a:b], self.v[:, a:b],
+                                   lr=o.lr, beta1=o.beta1, beta2=o.beta2, eps=o.eps, weight_decay=o.weight_decay,
+                                   t=step_index,
+                                   bc=self._bc_buf[step_index - 1] if self._bc_buf is not None else None)
         else:
             self.hip.sgdm_step(self.params, self.grads, self.m, lr=o.lr, momentum=o.momentum,
                                weight_decay=o.weight_decay)
@@ -386,8 +419,8 @@ class HipEngine(ShardEngine):
                 sidx = self._perm_buf[e, :, s * self.B:(s + 1) * self.B]
                 nv = nv_last if s == steps - 1 else self._nv(self.B)
                 self._forward(self.train_x, sidx, self.train_y, nv, "Train", train=True)
-                self._backward(self.train_x, sidx)
                 t += 1
+                self._backward(self.train_x, sidx, t)
                 self._optim_step(t)
             if self.val_x is not None:
                 self._eval_pass(self.val_x, self.val_y, "Validation")

@@ -295,7 +295,9 @@ class BatchedFederation:
                 cached = cached[:3] + (cached[3].to(self.device),) + cached[4:]
             self._plan_cache[key] = cached
         out = eng.alt_slab()
-        out.copy_(eng.params)            # rows nobody writes (dead / isolated nodes) keep their model
+        covered = set(train_sets) | set(adopt)
+        if any(i not in covered for i in self.local):
+            out.copy_(eng.params)        # rows nobody writes (dead / isolated nodes) keep their model
         if cached[0] == "allreduce":
             _, loc_src, loc_w, loc_dst = cached
             lo = self.local.start

@@ -5,13 +5,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _pair(name, K=3, n=64, n_val=16, n_test=40):
+def _pair(name, K=3, n=64, n_val=16, n_test=40, fuse=True):
     from p2pfl_amd.datasets.synthetic import synthetic_shards
     from p2pfl_amd.models.specs import get_spec
     from p2pfl_amd.runtime.engine import EagerEngine, HipEngine
     spec = get_spec(name)
     data = synthetic_shards(K, n, n_val, n_test, spec.num_classes, seed=3, device="cuda")
-    h = HipEngine(spec, K, "cuda", seed=11, use_graph=False)
+    h = HipEngine(spec, K, "cuda", seed=11, use_graph=False, fuse_optimizer=fuse)
     e = EagerEngine(spec, K, "cuda", seed=11)
     h.init_params(identical=False)
     e.params.copy_(h.params)
@@ -22,7 +22,7 @@ def _pair(name, K=3, n=64, n_val=16, n_test=40):
 
 @pytest.mark.parametrize("name", ["mnist-mlp", "mnist-cnn", "femnist-cnn"])
 def test_first_step_gradients_match_autograd(name):
-    spec, h, e = _pair(name)
+    spec, h, e = _pair(name, fuse=False)
     K, B = h.K, h.B
     sidx = torch.stack([torch.randperm(64, device="cuda")[:B] for _ in range(K)]).int()
     h.stats["Train"].zero_()

@@ -86,6 +86,28 @@ def test_linear_wgrad(K, B, In, Out):
     assert rel_err(db, dy.sum(1)) < 2e-2
 
 
+@pytest.mark.parametrize("K,B,In,Out", [(2, 32, 3136, 300), (1, 20, 130, 70)])
+def test_linear_wgrad_adam_matches_unfused(K, B, In, Out):
+    h = hip()
+    P = In * Out + 64 - (In * Out) % 64 + 512
+    slabs = [torch.randn(K, P, device=DEV) * 0.05 for _ in range(3)]
+    slabs[1].zero_(); slabs[2].zero_()
+    ref = [s.clone() for s in slabs]
+    grads = torch.zeros(K, P, device=DEV)
+    n = In * Out
+    view = lambda s: (s[:, :n].unflatten(1, (Out, In)), s[:, P - 512:P - 512 + Out])
+    for t in range(1, 4):
+        dy = torch.randn(K, B, Out, device=DEV)
+        x = torch.randn(K, B, In, device=DEV)
+        (w, b), (mw, mb), (vw, vb) = view(slabs[0]), view(slabs[1]), view(slabs[2])
+        h.linear_wgrad_adam(dy, x, w, mw, vw, b, mb, vb, lr=1e-3, t=t)
+        gw, gb = view(grads)
+        h.linear_wgrad(dy, x, gw, gb)
+        h.adam_step(ref[0], grads, ref[1], ref[2], lr=1e-3, t=t)
+    for a, r in zip(slabs, ref):
+        assert torch.allclose(a, r, atol=1e-6, rtol=1e-5)
+
+
 @pytest.mark.parametrize("ks", [5, 7])
 def test_conv1_fwd(ks):
     h = hip()

@@ -25,45 +25,38 @@ const char END[] = "\\PARAMS";      // 7 bytes
 constexpr size_t HDR_LEN = 6, END_LEN = 7;
 }  // namespace
 
-// Number of frames build_params produces for `n` payload bytes.
+// Every frame is exactly `block` bytes and starts with "PARAMS"; all frames but the last carry
+// block-6 payload bytes, the last carries the remaining (<= block-13, possibly 0) payload bytes,
+// then "\\PARAMS", then zero padding. (The reference emits an unpadded short data frame followed
+// by a 13-byte closing frame when the tail does not fit, communication_protocol.py:760-767, which
+// its own fixed-BLOCK_SIZE receiver mis-frames; any reference receiver parses this layout.)
 API size_t p2pfl_params_frame_count(size_t n, size_t block) {
     if (block <= HDR_LEN + END_LEN) return 0;
-    const size_t cap = block - HDR_LEN;
-    size_t frames = n ? (n + cap - 1) / cap : 1;
-    const size_t last = n ? n - (frames - 1) * cap : 0;
-    if (HDR_LEN + last + END_LEN > block) frames += 1;
+    const size_t cap = block - HDR_LEN, last_cap = cap - END_LEN;
+    size_t frames = 1;
+    while (n > last_cap) { n -= (n < cap ? n : cap); ++frames; }
     return frames;
 }
 
-// Writes frames back to back into out (capacity >= frames*block); every frame except possibly
-// a lone trailing "PARAMS\PARAMS" is exactly `block` bytes. Returns total bytes written and the
-// length of the last frame through *last_len (the reference leaves a separate closing frame
-// unpadded).
+// Writes the frames back to back into out (capacity frame_count*block); returns bytes written.
 API size_t p2pfl_params_build(const uint8_t* data, size_t n, size_t block, uint8_t* out, size_t* last_len) {
-    const size_t cap = block - HDR_LEN;
-    size_t off = 0, w = 0, last = 0;
-    if (n == 0) { std::memcpy(out, HDR, HDR_LEN); w = HDR_LEN; last = 0; }
-    while (off < n) {
+    const size_t cap = block - HDR_LEN, last_cap = cap - END_LEN;
+    size_t off = 0, w = 0;
+    while (n - off > last_cap) {
         const size_t take = (n - off < cap) ? n - off : cap;
         std::memcpy(out + w, HDR, HDR_LEN);
         std::memcpy(out + w + HDR_LEN, data + off, take);
+        if (take < cap) std::memset(out + w + HDR_LEN + take, 0, cap - take);   // unreachable: take == cap here
         off += take;
-        last = take;
-        w += HDR_LEN + take;
+        w += block;
     }
-    if (HDR_LEN + last + END_LEN <= block) {
-        std::memcpy(out + w, END, END_LEN);
-        w += END_LEN;
-        const size_t frame_len = HDR_LEN + last + END_LEN;
-        std::memset(out + w, 0, block - frame_len);
-        w += block - frame_len;
-        *last_len = block;
-    } else {
-        std::memcpy(out + w, HDR, HDR_LEN);
-        std::memcpy(out + w + HDR_LEN, END, END_LEN);
-        w += HDR_LEN + END_LEN;
-        *last_len = HDR_LEN + END_LEN;
-    }
+    const size_t rest = n - off;
+    std::memcpy(out + w, HDR, HDR_LEN);
+    std::memcpy(out + w + HDR_LEN, data + off, rest);
+    std::memcpy(out + w + HDR_LEN + rest, END, END_LEN);
+    std::memset(out + w + HDR_LEN + rest + END_LEN, 0, block - (HDR_LEN + rest + END_LEN));
+    w += block;
+    *last_len = block;
     return w;
 }
 

@@ -1,0 +1,68 @@
+"""CIFAR-10 data module (reference: fedstellar/learning/pytorch/cifar10/cifar10.py:20-116).
+
+Reads ``cifar10.npz`` (keys ``x_train [50000,32,32,3] uint8, y_train, x_test, y_test``) from
+``root_dir`` when present (the python-pickle batches of the original archive are not loaded:
+unpickling downloaded files is unsafe), otherwise a synthetic 3x32x32 10-class set. Training
+augmentation of the reference (RandomCrop(32, pad 4) + horizontal flip + Normalize,
+cifar10.py:62-69) is applied per batch by :meth:`augment`; test == validation set, ``drop_last``
+on the training loader (cifar10.py:76-77,115-116).
+"""
+from __future__ import annotations
+
+import logging
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ..datamodule import FederatedDataModule, synthetic_classification
+
+MEAN = torch.tensor([0.4914, 0.4822, 0.4465]).view(1, 3, 1, 1)
+STD = torch.tensor([0.2470, 0.2435, 0.2616]).view(1, 3, 1, 1)
+
+
+class CIFAR10DataModule(FederatedDataModule):
+    num_classes = 10
+    input_shape = (3, 32, 32)
+    cifar10_train = None
+    cifar10_val = None
+    synthetic = False
+
+    def __init__(self, sub_id=0, number_sub=1, batch_size=32, num_workers=4, val_percent=0.1, iid=True,
+                 root_dir=None, seed=0):
+        super().__init__(sub_id, number_sub, batch_size, num_workers, val_percent, iid, seed)
+        cls = CIFAR10DataModule
+        if cls.cifar10_train is None:
+            cls._load(root_dir or os.path.join(os.getcwd(), "data"))
+        self._install(*cls.cifar10_train, *cls.cifar10_val, drop_val=True)
+        self.val_x, self.val_y = self.test_x, self.test_y   # reference: val loader == test loader
+
+    @classmethod
+    def _load(cls, root):
+        path = os.path.join(root, "cifar10.npz")
+        if os.path.exists(path):
+            d = np.load(path)
+            prep = lambda a: (torch.from_numpy(a).permute(0, 3, 1, 2).float() / 255.0 - MEAN) / STD
+            cls.cifar10_train = (prep(d["x_train"]).reshape(len(d["x_train"]), -1), torch.from_numpy(d["y_train"]).long().flatten())
+            cls.cifar10_val = (prep(d["x_test"]).reshape(len(d["x_test"]), -1), torch.from_numpy(d["y_test"]).long().flatten())
+            cls.synthetic = False
+        else:
+            logging.warning("[CIFAR10] %s not found: using the synthetic CIFAR-shaped set", path)
+            tx, ty, ex, ey = synthetic_classification(50000, 10000, 3 * 32 * 32, 10, seed=777, binary_images=False)
+            cls.cifar10_train, cls.cifar10_val, cls.synthetic = (tx, ty), (ex, ey), True
+
+    @staticmethod
+    def augment(x: torch.Tensor, generator=None) -> torch.Tensor:
+        """RandomCrop(32, padding=4) + RandomHorizontalFlip on a [B,3,32,32] batch."""
+        b = x.shape[0]
+        xp = F.pad(x, (4, 4, 4, 4))
+        ox = torch.randint(0, 9, (b,), generator=generator)
+        oy = torch.randint(0, 9, (b,), generator=generator)
+        out = torch.stack([xp[i, :, oy[i]:oy[i] + 32, ox[i]:ox[i] + 32] for i in range(b)])
+        flip = torch.rand(b, generator=generator) < 0.5
+        out[flip] = out[flip].flip(-1)
+        return out
+
+    def train_dataloader(self):
+        return self._loader(self.train_x, self.train_y, True, drop_last=True)

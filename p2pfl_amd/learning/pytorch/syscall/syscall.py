@@ -1,0 +1,53 @@
+"""SYSCALL (malware system-call frequency) data module
+(reference: fedstellar/learning/pytorch/syscall/syscall.py:21-218).
+
+17 scaled 1-gram system-call frequency features, 9 classes, 85/15 train/test split, validation =
+1 % of the shard (syscall.py:60-112,139-181). The reference downloads a zip of CSVs; here
+``syscall.pt`` (``(x_train, y_train, x_test, y_test)`` tensors, ``weights_only=True``) or
+``syscall.csv`` (17 feature columns + label column) under ``root_dir`` are used when present,
+otherwise a synthetic set of the same shape.
+"""
+from __future__ import annotations
+
+import logging
+import os
+
+import torch
+
+from ..datamodule import FederatedDataModule, synthetic_classification
+
+
+class SYSCALLDataModule(FederatedDataModule):
+    num_classes = 9
+    input_shape = (17,)
+    train_set = None
+    test_set = None
+    synthetic = False
+
+    def __init__(self, sub_id=0, number_sub=1, batch_size=32, num_workers=4, val_percent=0.01, iid=True,
+                 root_dir=None, seed=0):
+        super().__init__(sub_id, number_sub, batch_size, num_workers, val_percent, iid, seed)
+        cls = SYSCALLDataModule
+        if cls.train_set is None:
+            cls._load(root_dir or os.path.join(os.getcwd(), "data", "syscall"))
+        self._install(*cls.train_set, *cls.test_set)
+
+    @classmethod
+    def _load(cls, root):
+        pt, csv = os.path.join(root, "syscall.pt"), os.path.join(root, "syscall.csv")
+        if os.path.exists(pt):
+            tx, ty, ex, ey = torch.load(pt, weights_only=True)
+            cls.synthetic = False
+        elif os.path.exists(csv):
+            import numpy as np
+            a = np.loadtxt(csv, delimiter=",", skiprows=1)
+            x, y = torch.from_numpy(a[:, :17]).float(), torch.from_numpy(a[:, 17]).long()
+            perm = torch.randperm(len(x), generator=torch.Generator().manual_seed(0))
+            cut = int(len(x) * 0.85)
+            tx, ty, ex, ey = x[perm[:cut]], y[perm[:cut]], x[perm[cut:]], y[perm[cut:]]
+            cls.synthetic = False
+        else:
+            logging.warning("[SYSCALL] no data under %s: using the synthetic set", root)
+            tx, ty, ex, ey = synthetic_classification(17000, 3000, 17, 9, seed=99, noise=0.15, binary_images=False)
+            cls.synthetic = True
+        cls.train_set, cls.test_set = (tx.float(), ty.long()), (ex.float(), ey.long())

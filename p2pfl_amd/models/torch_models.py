@@ -31,11 +31,23 @@ class FederatedModule(nn.Module):
         self.criterion = nn.CrossEntropyLoss()
         self.example_input_array = torch.zeros(1, 1, 28, 28)
 
+    is_classifier = True        # metrics are derived from a confusion matrix of argmax predictions
+
     @property
-    def spec(self) -> specs.ModelSpec:
+    def spec(self):
+        """:class:`ModelSpec` for models the client-batched HIP engine can execute, else None."""
+        if type(self).spec_factory is None:
+            return None
         return type(self).spec_factory(num_classes=self.out_channels, lr=self.learning_rate)
 
+    def training_loss(self, x, y):
+        """(loss, predictions-or-None) of one batch; overridden by non-classification models."""
+        out = self(x)
+        return self.criterion(out, y), out.detach().argmax(dim=1)
+
     def configure_optimizers(self):
+        if self.spec is None:
+            return torch.optim.Adam(self.parameters(), lr=self.learning_rate)
         o = self.spec.optim
         if o.kind == "adam":
             return torch.optim.Adam(self.parameters(), lr=o.lr, betas=(o.beta1, o.beta2), eps=o.eps,

@@ -1,0 +1,107 @@
+"""TCP loopback federations of real Node objects (wire protocol + gossip + aggregation)."""
+import time
+
+import pytest
+import torch
+
+from p2pfl_amd.config import Config
+from p2pfl_amd.config.config import fast_timings
+from p2pfl_amd.learning.pytorch.mnist.mnist import MNISTDataModule
+from p2pfl_amd.learning.pytorch.mnist.models.mlp import MNISTModelMLP
+from p2pfl_amd.node import Node
+from p2pfl_amd.role import Role
+
+
+def make_config(role=Role.AGGREGATOR, federation="DFL", n=2, idx=0):
+    c = Config(participant={"scenario_args": {"federation": federation, "n_nodes": n, "name": "", "controller": ""},
+                            "device_args": {"role": role, "idx": idx, "accelerator": "cpu"},
+                            "tracking_args": {"local_tracking": "none", "log_dir": ""}})
+    fast_timings(c.participant, 0.02)
+    c.participant["AGGREGATION_TIMEOUT"] = 20
+    c.participant["NODE_TIMEOUT"] = 20
+    return c
+
+
+def make_nodes(n, roles, federation="DFL", encrypt=False, number_sub=200):
+    nodes = []
+    for i in range(n):
+        data = MNISTDataModule(sub_id=i, number_sub=number_sub)
+        node = Node(i, "test", MNISTModelMLP(seed=100 + i), data, config=make_config(roles[i], federation, n, i),
+                    encrypt=encrypt)
+        node.start()
+        nodes.append(node)
+    return nodes
+
+
+def wait_finished(nodes, timeout=120):
+    t0 = time.time()
+    started = False
+    while time.time() - t0 < timeout:
+        rounds = [n.round for n in nodes]
+        if any(r is not None for r in rounds):
+            started = True
+        if started and all(r is None for r in rounds):
+            return True
+        time.sleep(0.1)
+    return False
+
+
+def stop_all(nodes):
+    for n in nodes:
+        n.stop()
+    time.sleep(0.3)
+
+
+def models_equal(a, b, tol=1e-6):
+    sa, sb = a.learner.get_parameters(), b.learner.get_parameters()
+    return all(torch.allclose(sa[k], sb[k], atol=tol) for k in sa)
+
+
+@pytest.mark.parametrize("encrypt", [False, True])
+def test_two_node_dfl_mlp_fully_connected(encrypt):
+    nodes = make_nodes(2, [Role.AGGREGATOR] * 2, encrypt=encrypt)
+    try:
+        assert nodes[0].connect_to(nodes[1].host, nodes[1].port) is not None
+        time.sleep(0.5)
+        assert nodes[1].get_neighbors_names() == [nodes[0].get_name()]
+        assert not models_equal(nodes[0], nodes[1])
+        nodes[0].set_start_learning(rounds=2, epochs=1)
+        assert wait_finished(nodes)
+        assert all(n.round is None for n in nodes)
+        assert models_equal(nodes[0], nodes[1])       # both averaged the same two models
+    finally:
+        stop_all(nodes)
+
+
+def test_three_node_cfl_star_server_never_trains():
+    nodes = make_nodes(3, [Role.SERVER, Role.TRAINER, Role.TRAINER], federation="CFL")
+    try:
+        for i in (1, 2):
+            assert nodes[i].connect_to(nodes[0].host, nodes[0].port) is not None
+        time.sleep(0.5)
+        fits = []
+        orig = nodes[0].learner.fit
+        nodes[0].learner.fit = lambda: fits.append(1) or orig()
+        nodes[0].set_start_learning(rounds=2, epochs=1)
+        assert wait_finished(nodes)
+        assert fits == []                              # the CFL server only aggregates
+        assert models_equal(nodes[0], nodes[1]) and models_equal(nodes[0], nodes[2])
+    finally:
+        stop_all(nodes)
+
+
+def test_connections_refused_while_learning_and_dead_neighbor_eviction():
+    nodes = make_nodes(3, [Role.AGGREGATOR] * 3)
+    try:
+        nodes[0].connect_to(nodes[1].host, nodes[1].port)
+        time.sleep(0.3)
+        nodes[0].round = 0                             # pretend learning is running
+        assert nodes[0].connect_to(nodes[2].host, nodes[2].port) is None
+        nodes[0].round = None
+        nodes[1].stop()
+        t0 = time.time()
+        while nodes[0].get_neighbors() and time.time() - t0 < 10:
+            time.sleep(0.1)
+        assert nodes[0].get_neighbors() == []          # END_CONNECTION -> rm_neighbor
+    finally:
+        stop_all(nodes)

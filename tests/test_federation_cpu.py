@@ -1,0 +1,164 @@
+"""BatchedFederation semantics on the CPU (eager engine) incl. 2-rank gloo exchange."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from p2pfl_amd.datasets.synthetic import synthetic_shards
+from p2pfl_amd.models.specs import get_spec
+from p2pfl_amd.role import Role
+from p2pfl_amd.runtime.federation import BatchedFederation, partition_nodes
+from p2pfl_amd.utils.topologymanager import TopologyManager
+
+SPEC = get_spec("mnist-mlp")
+
+
+def topo(kind, n, seed=0):
+    tm = TopologyManager(n_nodes=n, undirected_neighbor_num=n - 1 if kind == "fully" else 3, seed=seed)
+    if kind == "fully":
+        tm.generate_topology()
+    elif kind == "ring":
+        tm.generate_ring_topology()
+    elif kind == "star":
+        tm.generate_server_topology()
+    else:
+        tm.generate_topology(extra_random_links=1.5)
+    return tm.topology
+
+
+def make_fed(kind, n, federation="DFL", rank=0, world=1, pg=None, encrypt=False, n_train=32):
+    fed = BatchedFederation(SPEC, topo(kind, n), federation=federation, device="cpu", engine="eager", epochs=1, seed=5,
+                            rank=rank, world_size=world, process_group=pg, encrypt=encrypt)
+    data = synthetic_shards(fed.n_local, n_train, 8, 16, 10, seed=1, first_client=fed.local.start)
+    fed.init_params()
+    fed.set_local_data(*data)
+    return fed
+
+
+def perturb(fed):
+    """Deterministic stand-in for local training: row of node g becomes base + (g+1)/100."""
+    def fit(epochs, active=None):
+        for k, g in enumerate(fed.local):
+            if active is None or bool(active[k]):
+                fed.engine.params[k] += (g + 1) / 100.0
+        return {}
+    fed.engine.fit = fit
+
+
+def test_partition():
+    assert [list(r) for r in partition_nodes(5, 2)] == [[0, 1, 2], [3, 4]]
+
+
+def test_dfl_fully_connected_all_nodes_identical_and_learning():
+    fed = make_fed("fully", 4)
+    reps = fed.run(2)
+    p = fed.engine.params
+    assert all(torch.equal(p[0], p[k]) for k in range(1, 4))
+    assert reps[0].train_samples == 4 * 32 and reps[1].test_loss.mean() < reps[0].test_loss.mean()
+
+
+def test_ring_each_node_averages_its_train_set():
+    fed = make_fed("ring", 5)
+    perturb(fed)
+    base = fed.engine.params[0, 0].item()
+    fed.run_round(evaluate=False)
+    for i in range(5):
+        ts = [(i - 1) % 5, i, (i + 1) % 5]
+        expect = base + np.mean([(g + 1) / 100.0 for g in ts])
+        assert abs(fed.engine.params[i, 0].item() - expect) < 1e-6
+
+
+def test_weighted_average_uses_training_set_sizes():
+    fed = make_fed("fully", 3)
+    fed.weights[:] = [100, 300, 600]
+    perturb(fed)
+    base = fed.engine.params[0, 0].item()
+    fed.run_round(evaluate=False)
+    assert abs(fed.engine.params[2, 0].item() - (base + (0.01 * 100 + 0.02 * 300 + 0.03 * 600) / 1000)) < 1e-6
+
+
+def test_cfl_server_never_trains_and_trainers_adopt():
+    fed = make_fed("star", 4, federation="CFL")
+    assert fed.roles == [Role.SERVER] + [Role.TRAINER] * 3
+    seen = {}
+    orig = fed.engine.fit
+    fed.engine.fit = lambda e, active=None: seen.setdefault("a", active.clone()) is None or orig(e, active)
+    fed.run_round()
+    assert seen["a"].tolist() == [False, True, True, True]
+    p = fed.engine.params
+    assert all(torch.equal(p[0], p[k]) for k in range(1, 4))     # server aggregate diffused to every trainer
+
+
+def test_sdfl_leadership_moves_and_stays_unique():
+    fed = make_fed("fully", 4, federation="SDFL")
+    leaders = []
+    for _ in range(4):
+        leaders.append(fed.roles.index(Role.AGGREGATOR))
+        fed.run_round(evaluate=False)
+        assert fed.roles.count(Role.AGGREGATOR) == 1
+        p = fed.engine.params
+        assert all(torch.equal(p[0], p[k]) for k in range(1, 4))
+    assert len(set(leaders)) > 1
+
+
+def test_idle_and_proxy_nodes_adopt_without_contributing():
+    roles = [Role.AGGREGATOR, Role.AGGREGATOR, Role.IDLE, Role.PROXY]
+    fed = BatchedFederation(SPEC, topo("fully", 4), roles=roles, device="cpu", engine="eager", seed=5)
+    fed.init_params()
+    fed.set_local_data(*synthetic_shards(4, 32, 8, 16, 10, seed=1))
+    perturb(fed)
+    base = fed.engine.params[0, 0].item()
+    fed.run_round(evaluate=False)
+    expect = base + (0.01 + 0.02) / 2            # only the two aggregators trained and contributed
+    assert all(abs(fed.engine.params[k, 0].item() - expect) < 1e-6 for k in range(4))
+
+
+def test_killed_node_is_dropped_from_train_sets_and_keeps_its_model():
+    fed = make_fed("ring", 5)
+    perturb(fed)
+    base = fed.engine.params[0, 0].item()
+    fed.schedule_fault(0, "kill", 2)
+    fed.run_round(evaluate=False)
+    assert abs(fed.engine.params[2, 0].item() - base) < 1e-7            # dead: neither trained nor aggregated
+    assert abs(fed.engine.params[1, 0].item() - (base + (0.01 + 0.02) / 2)) < 1e-6   # neighbours 0,1 only
+    fed.schedule_fault(1, "revive", 2)
+    fed.run_round(evaluate=False)
+    assert fed.alive.all()
+
+
+# ------------------------------------------------------------------ 2 ranks over gloo
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, kind, encrypt, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    fed = make_fed(kind, 6, rank=rank, world=world, pg=dist.group.WORLD, encrypt=encrypt)
+    perturb(fed)
+    fed.run_round(evaluate=False)
+    fed.run_round(evaluate=False)
+    out[rank] = fed.engine.params[:, :8].clone()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,encrypt", [("ring", False), ("random", True), ("fully", False), ("fully", True)])
+def test_two_rank_exchange_matches_single_rank(kind, encrypt):
+    ref = make_fed(kind, 6)
+    perturb(ref)
+    ref.run_round(evaluate=False)
+    ref.run_round(evaluate=False)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), kind, encrypt, out), nprocs=2, join=True)
+    got = torch.cat([out[0], out[1]], dim=0)
+    assert torch.allclose(got, ref.engine.params[:, :8], atol=1e-6)

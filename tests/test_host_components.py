@@ -1,0 +1,221 @@
+"""Config, topology, roles, observer, heartbeater (fake clock), gossiper budget, codec, aggregator."""
+import pickle
+import threading
+import time
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from p2pfl_amd.config import Config
+from p2pfl_amd.gossiper import Gossiper
+from p2pfl_amd.heartbeater import Heartbeater
+from p2pfl_amd.learning import codec
+from p2pfl_amd.learning.aggregators.fedavg import FedAvg
+from p2pfl_amd.learning.exceptions import DecodingParamsError
+from p2pfl_amd.learning.metrics import metrics_from_confusion
+from p2pfl_amd.role import Role, default_roles
+from p2pfl_amd.utils.observer import Events, Observable, Observer
+from p2pfl_amd.utils.topologymanager import TopologyManager
+
+
+# ---------------------------------------------------------------- config
+def test_config_defaults_block_size_and_validation(tmp_path):
+    c = Config(participant={"BLOCK_SIZE": 2050})
+    assert c.participant["BLOCK_SIZE"] == 2064 and c.participant["BLOCK_SIZE"] % 16 == 0
+    assert c.participant["GOSSIP_MODELS_PER_ROUND"] == 2 and c.participant["device_args"]["role"] == "aggregator"
+    import json
+    p = tmp_path / "participant_0.json"
+    p.write_text(json.dumps({"scenario_args": {"federation": "XFL"}}))
+    with pytest.raises(ValueError):
+        Config(participant_config_file=str(p))
+    p.write_text(json.dumps({"scenario_args": {"federation": "CFL", "rounds": 7}, "device_args": {"role": "server"}}))
+    c = Config(participant_config_file=str(p))
+    assert c.participant["scenario_args"]["rounds"] == 7 and c.participant["NODE_TIMEOUT"] == 20
+    c2 = pickle.loads(pickle.dumps(c))
+    assert c2.participant == c.participant
+
+
+# ---------------------------------------------------------------- topology
+@pytest.mark.parametrize("n", [3, 10, 33])
+def test_topology_invariants(n):
+    tm = TopologyManager(n_nodes=n, undirected_neighbor_num=n - 1)
+    tm.generate_topology()
+    t = tm.topology
+    assert tm.b_fully_connected and (t.sum(1) == n - 1).all() and np.trace(t) == 0
+    tm = TopologyManager(n_nodes=n, undirected_neighbor_num=2)
+    tm.generate_ring_topology()
+    t = tm.topology
+    assert (t == t.T).all() and np.trace(t) == 0 and (t.sum(1) == (2 if n > 2 else 1)).all()
+    tm.generate_server_topology()
+    t = tm.topology
+    assert t[0, 1:].all() and t[1:, 0].all() and t[1:, 1:].sum() == 0
+    if n > 4:
+        tm = TopologyManager(n_nodes=n, undirected_neighbor_num=3, seed=3)
+        tm.generate_topology(extra_random_links=2.0)
+        t = tm.topology
+        assert (t == t.T).all() and np.trace(t) == 0 and (t.sum(1) >= 2).all()
+        tm2 = TopologyManager(n_nodes=n, undirected_neighbor_num=3, seed=3)
+        tm2.generate_topology(extra_random_links=2.0)
+        assert (tm2.topology == t).all()           # seeded => every rank builds the same graph
+
+
+def test_topology_neighbors_string_and_custom():
+    tm = TopologyManager(n_nodes=3, undirected_neighbor_num=2)
+    tm.generate_custom_topology([[0, 1, 0], [1, 0, 1], [0, 1, 0]])
+    tm.add_nodes([("127.0.0.1", 45000 + i, "aggregator", None) for i in range(3)])
+    assert tm.get_neighbors_string(1) == "127.0.0.1:45000 127.0.0.1:45002"
+    assert tm.get_neighbors(0)[0] == [1]
+    with pytest.raises(ValueError):
+        TopologyManager(n_nodes=3, undirected_neighbor_num=1)
+
+
+def test_default_roles():
+    assert default_roles("DFL", 3) == [Role.AGGREGATOR] * 3
+    assert default_roles("SDFL", 3) == [Role.AGGREGATOR, Role.TRAINER, Role.TRAINER]
+    assert default_roles("CFL", 3) == [Role.SERVER, Role.TRAINER, Role.TRAINER]
+    assert not Role.trains(Role.SERVER) and Role.waits(Role.IDLE) and Role.aggregates(Role.SERVER)
+
+
+# ---------------------------------------------------------------- observer
+def test_observer_isolation_of_failing_observers():
+    got = []
+
+    class Bad(Observer):
+        def update(self, e, o):
+            raise RuntimeError("boom")
+
+    class Good(Observer):
+        def update(self, e, o):
+            got.append((e, o))
+
+    ob = Observable()
+    ob.add_observer(Bad())
+    ob.add_observer(Good())
+    ob.notify(Events.BEAT_RECEIVED_EVENT, "n")
+    assert got == [(Events.BEAT_RECEIVED_EVENT, "n")]
+
+
+# ---------------------------------------------------------------- heartbeater / gossiper
+def test_heartbeater_eviction_with_fake_clock():
+    now = [1000.0]
+    hb = Heartbeater("me:1", lambda: [], Config(participant={"NODE_TIMEOUT": 20}), clock=lambda: now[0])
+    hb.add_node("a:1")
+    hb.add_node("me:1")                      # own beats are ignored
+    hb.add_node_role("a:1", "trainer")
+    now[0] += 10
+    hb.add_node("b:2")                       # no role ever received: eviction must not raise (reference KeyError)
+    assert sorted(hb.get_nodes()) == ["a:1", "b:2", "me:1"]
+    now[0] += 11
+    assert hb.clear_nodes() == ["a:1"]
+    assert sorted(hb.get_nodes()) == ["b:2", "me:1"] and "a:1" not in hb.get_nodes_role()
+    now[0] += 25
+    hb.clear_nodes()
+    assert hb.get_nodes() == ["me:1"]
+
+
+def test_gossiper_budget_and_exclusion():
+    class NC:
+        def __init__(self, n):
+            self.n = n
+
+        def get_name(self):
+            return self.n
+
+    ncs = [NC("a"), NC("b"), NC("c")]
+    sent = []
+
+    class Sink(Observer):
+        def update(self, e, o):
+            sent.append((e, o[0], [x.get_name() for x in o[1]]))
+
+    g = Gossiper("me", lambda: ncs, Config(participant={"GOSSIP_MESSAGES_FREC": 20, "GOSSIP_MESSAGES_PER_ROUND": 2}))
+    g.add_observer(Sink())
+    g.add_messages([b"m1", b"m2", b"m3", b"m4", b"m5"], ncs[0])
+    g.start()
+    time.sleep(0.08)                         # ~2 ticks of 50 ms with a budget of 2 each
+    n_early = len(sent)
+    time.sleep(0.3)
+    g.stop()
+    assert 2 <= n_early <= 4 and len(sent) == 5
+    assert all(e == Events.GOSSIP_BROADCAST_EVENT and excl == ["a"] for e, _, excl in sent)
+
+
+# ---------------------------------------------------------------- codec
+def test_payload_is_reference_compatible_and_safe(tmp_path):
+    arrays = [np.random.rand(3, 4).astype(np.float32), np.arange(5, dtype=np.int64)]
+    blob = codec.encode_parameters(arrays, ["a:1"], 540)
+    a, c, w = pickle.loads(blob)             # what a reference node does (lightninglearner.py:81)
+    assert isinstance(a, list) and isinstance(a[0], np.ndarray) and c == ["a:1"] and w == 540
+    a2, c2, w2 = codec.decode_parameters(blob)
+    assert all((x == y).all() for x, y in zip(arrays, a2)) and (c2, w2) == (["a:1"], 540)
+    assert codec.decode_parameters(codec.encode_parameters(arrays))[1:] == (None, None)
+    import os
+    with pytest.raises(DecodingParamsError):
+        codec.decode_parameters(pickle.dumps((os.system, None, None)))
+    with pytest.raises(DecodingParamsError):
+        codec.decode_parameters(b"not a pickle")
+    path = str(tmp_path / "ck" / "m.ckpt")
+    codec.save_checkpoint(path, arrays, ["a:1"], 10, meta={"round": 3})
+    a3, c3, w3, meta = codec.load_checkpoint(path)
+    assert (a3[0] == arrays[0]).all() and meta == {"round": 3}
+
+
+# ---------------------------------------------------------------- aggregator
+class Catch(Observer):
+    def __init__(self):
+        self.events = []
+
+    def update(self, e, o):
+        self.events.append((e, o))
+
+
+def _sd(v):
+    return OrderedDict(w=torch.full((2, 3), float(v)), b=torch.full((3,), float(v)), n=torch.tensor(int(v)))
+
+
+def test_aggregator_bookkeeping_partial_waiting_timeout():
+    cfg = Config(participant={"AGGREGATION_TIMEOUT": 0.5})
+    agg, obs = FedAvg("n1", cfg), Catch()
+    agg.add_observer(obs)
+    agg.set_nodes_to_aggregate(["n1", "n2", "n3"])
+    assert agg.add_model(_sd(1), ["n1"], 10) == ["n1"]
+    assert agg.add_model(_sd(2), ["n2"], 30) == ["n1", "n2"]
+    assert agg.add_model(_sd(9), ["n2", "n3"], 5) is None           # overlapping contributors rejected
+    m, c, w = agg.get_partial_aggregation(["n1"])
+    assert c == ["n2"] and w == 30 and torch.allclose(m["w"], torch.full((2, 3), 2.0))
+    assert agg.get_partial_aggregation(["n1", "n2"]) == (None, None, None)
+    assert agg.add_model(_sd(3), ["n3"], 60) == ["n1", "n2", "n3"]
+    assert agg.wait_aggregation(5)
+    e, model = obs.events[-1]
+    assert e == Events.AGGREGATION_FINISHED_EVENT
+    assert torch.allclose(model["w"], torch.full((2, 3), 2.5)) and int(model["n"]) == 3   # ints: max, not mean
+    # timeout with a missing model
+    agg.clear()
+    agg.set_nodes_to_aggregate(["n1", "n2"])
+    agg.add_model(_sd(4), ["n1"], 10)
+    t0 = time.time()
+    assert agg.wait_aggregation(5) and 0.4 < time.time() - t0 < 3
+    assert torch.allclose(obs.events[-1][1]["w"], torch.full((2, 3), 4.0))
+    # waiting mode adopts whatever arrives
+    agg.clear()
+    agg.set_waiting_aggregated_model()
+    assert agg.add_model(_sd(7), None, None) is None
+    assert torch.allclose(obs.events[-1][1]["w"], torch.full((2, 3), 7.0))
+    # empty train set -> AGGREGATION_FINISHED(None) is not raised by add_model on a cleared round
+    agg.clear()
+    n = len(obs.events)
+    agg.add_model(_sd(1), ["n1"], 1)
+    assert len(obs.events) == n
+
+
+def test_macro_metrics_match_sklearn():
+    from sklearn.metrics import confusion_matrix, f1_score, precision_score, recall_score
+    rng = np.random.RandomState(0)
+    y, p = rng.randint(0, 6, 500), rng.randint(0, 6, 500)
+    m = metrics_from_confusion(torch.from_numpy(confusion_matrix(y, p, labels=list(range(6)))))
+    assert abs(m["Precision"] - precision_score(y, p, average="macro")) < 1e-9
+    assert abs(m["Recall"] - recall_score(y, p, average="macro")) < 1e-9
+    assert abs(m["F1Score"] - f1_score(y, p, average="macro")) < 1e-9
+    assert abs(m["Accuracy"] - recall_score(y, p, average="macro")) < 1e-9

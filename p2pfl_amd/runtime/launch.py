@@ -1,0 +1,179 @@
+"""Scenario launcher for the batched (one process per GPU) execution model.
+
+``python -m p2pfl_amd.runtime.launch <scenario config dir> [--device cuda|cpu] [--encrypt]`` — or under
+``torch.distributed.run`` with one rank per GPU — runs a whole scenario that the controller
+prepared as ``participant_<i>.json`` files (the same files the per-process ``node_start`` consumes,
+reference controller.py:272-298): topology from the ``neighbors`` strings, roles / federation /
+rounds / epochs / dataset / model from the participant configs. Every rank hosts a contiguous block
+of the nodes in one :class:`BatchedFederation`.
+
+Per node it keeps the reference's observable artefacts: ``<log_dir>/<scenario>/participant_<i>.log``,
+``metrics/participant_<i>/metrics.csv`` (Test/Train/Validation Loss + macro metrics per round), a
+status POST of the live participant config to the controller, and (optionally) a final checkpoint
+in the payload format.
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import json
+import logging
+import os
+import sys
+import time
+from typing import List
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ..config.config import _deep_update, default_participant
+from ..learning.codec import save_checkpoint
+from ..learning.metrics import metrics_from_confusion
+from ..learning.pytorch.statisticslogger import CSVLogger
+from ..models.specs import get_spec
+from ..node_start import build_dataset_and_model
+from .federation import BatchedFederation
+
+_SPEC_OF = {("MNIST", "MLP"): "mnist-mlp", ("MNIST", "CNN"): "mnist-cnn", ("FEMNIST", "CNN"): "femnist-cnn"}
+
+
+def load_participants(config_dir: str) -> List[dict]:
+    files = sorted(glob.glob(os.path.join(config_dir, "participant_*.json")),
+                   key=lambda p: int(os.path.basename(p).split("_")[1].split(".")[0]))
+    if not files:
+        raise ValueError(f"No participant files found in {config_dir}")
+    out = []
+    for f in files:
+        with open(f) as fh:
+            out.append(_deep_update(default_participant(), json.load(fh)))
+    return out
+
+
+def adjacency_from_participants(parts: List[dict]) -> np.ndarray:
+    names = [f"{p['network_args']['ip']}:{p['network_args']['port']}" for p in parts]
+    index = {n: i for i, n in enumerate(names)}
+    adj = np.zeros((len(parts), len(parts)), dtype=np.float32)
+    for i, p in enumerate(parts):
+        for nb in p["network_args"]["neighbors"].split():
+            if nb in index and index[nb] != i:
+                adj[i, index[nb]] = adj[index[nb], i] = 1     # links are bidirectional sockets
+    return adj
+
+
+def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, save_models: bool = False,
+                 rounds: int = None) -> dict:
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if device == "auto":
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+    dev = torch.device(device, local_rank) if device == "cuda" else torch.device("cpu")
+    if device == "cuda":
+        torch.cuda.set_device(local_rank)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if device == "cuda" else "gloo", rank=rank, world_size=world)
+        pg = dist.group.WORLD
+
+    parts = load_participants(config_dir)
+    p0 = parts[0]
+    n = len(parts)
+    key = (p0["data_args"]["dataset"], p0["model_args"]["model"])
+    if key not in _SPEC_OF:
+        raise ValueError(f"the batched engine runs {sorted(_SPEC_OF)}; {key} needs the per-process node_start path")
+    spec = get_spec(_SPEC_OF[key])
+    scenario = p0["scenario_args"]["name"] or os.path.basename(os.path.normpath(config_dir))
+    federation = p0["scenario_args"]["federation"]
+    roles = [p["device_args"]["role"] for p in parts]
+    rounds = rounds or int(p0["scenario_args"]["rounds"])
+    epochs = int(p0["training_args"]["epochs"])
+
+    fed = BatchedFederation(spec, adjacency_from_participants(parts), federation=federation, roles=roles, device=dev,
+                            epochs=epochs, seed=int(p0["scenario_args"].get("random_seed", 0)), rank=rank,
+                            world_size=world, process_group=pg, encrypt=encrypt, scenario=scenario)
+    # data shards of the local nodes (real files when present, synthetic otherwise)
+    shards = [build_dataset_and_model(key[0], key[1], i, n, p0["data_args"].get("root_dir"))[0] for i in fed.local]
+    stack = lambda idx: None if shards[0].tensors()[idx] is None else torch.stack([s.tensors()[idx] for s in shards])
+    fed.init_params()
+    fed.set_local_data(*(stack(i) for i in range(6)))
+
+    log_root = os.path.join(p0["tracking_args"].get("log_dir") or "logs", scenario)
+    os.makedirs(log_root, exist_ok=True)
+    loggers = {i: CSVLogger(log_root, name="metrics", version=f"participant_{i}") for i in fed.local}
+    node_logs = {i: open(os.path.join(log_root, f"participant_{i}.log"), "a") for i in fed.local}
+
+    def node_log(i, msg):
+        node_logs[i].write(f"[{time.strftime('%Y-%m-%d %H:%M:%S')}] {msg}\n")
+        node_logs[i].flush()
+
+    def post_status(i):
+        ctrl = parts[i]["scenario_args"].get("controller")
+        if not ctrl:
+            return
+        try:
+            import requests
+            cfgp = dict(parts[i])
+            cfgp["device_args"] = dict(cfgp["device_args"], role=fed.roles[i])
+            requests.post(f"http://{ctrl}/scenario/{scenario}/node/update", data=json.dumps(cfgp),
+                          headers={"Content-Type": "application/json"}, timeout=1)
+        except Exception:
+            pass
+
+    t0 = time.time()
+    total_samples = 0
+    for r in range(rounds):
+        rep = fed.run_round()
+        total_samples += rep.train_samples
+        test = fed.engine.stats["Test"].summary()
+        train = fed.engine.stats["Train"].summary()
+        for k, i in enumerate(fed.local):
+            m = {"Round": r, "Test/Loss": float(test["loss"][k]), "Train/Loss": float(train["loss"][k])}
+            for ph, st in (("Test", test), ("Train", train)):
+                for name, v in metrics_from_confusion(st["confusion"][k]).items():
+                    if name != "MicroAccuracy":
+                        m[f"{ph}Epoch/{name}"] = v
+            loggers[i].log_metrics_direct(m, r)
+            node_log(i, f"round {r} role {fed.roles[i]} alive {bool(fed.alive[i])} test_loss {m['Test/Loss']:.4f} "
+                        f"test_acc {m['TestEpoch/Accuracy']:.4f} ({rep.seconds:.3f}s)")
+            if r % 2 == 0:
+                post_status(i)
+    final = fed.engine.evaluate()
+    elapsed = time.time() - t0
+    if save_models:
+        for k, i in enumerate(fed.local):
+            save_checkpoint(os.path.join(log_root, f"participant_{i}_final.ckpt"),
+                            fed.engine.layout.row_to_arrays(fed.engine.params[k]),
+                            [f"{parts[i]['network_args']['ip']}:{parts[i]['network_args']['port']}"],
+                            int(fed.weights[i]), meta={"round": rounds, "role": fed.roles[i]})
+    for f in node_logs.values():
+        f.close()
+    for lg in loggers.values():
+        lg.finalize()
+    summary = {"scenario": scenario, "rank": rank, "world": world, "nodes": n, "local_nodes": fed.n_local,
+               "rounds": rounds, "seconds": elapsed, "rounds_per_sec": rounds / elapsed,
+               "samples_per_sec": total_samples / elapsed, "final_test_accuracy": float(final["accuracy"].mean()),
+               "final_test_loss": float(final["loss"].mean())}
+    if rank == 0:
+        with open(os.path.join(log_root, "summary.json"), "w") as f:
+            json.dump(summary, f, indent=2)
+    if world > 1:
+        dist.destroy_process_group()
+    return summary
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument("config_dir")
+    ap.add_argument("--device", default="auto", choices=["auto", "cuda", "cpu"])
+    ap.add_argument("--encrypt", action="store_true")
+    ap.add_argument("--save-models", action="store_true")
+    ap.add_argument("--rounds", type=int, default=None)
+    a = ap.parse_args(argv)
+    logging.basicConfig(level=logging.INFO)
+    print(json.dumps(run_scenario(a.config_dir, a.device, a.encrypt, a.save_models, a.rounds)), flush=True)
+
+
+if __name__ == "__main__":
+    main()

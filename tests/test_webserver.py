@@ -1,0 +1,161 @@
+"""Frontend tests with Flask's test client (the reference ships no webserver tests; routes and
+payloads follow fedstellar/webserver/app.py:60-723)."""
+import datetime
+import importlib
+import io
+import json
+import os
+import zipfile
+
+import pytest
+
+flask = pytest.importorskip("flask")
+
+
+@pytest.fixture()
+def web(tmp_path, monkeypatch):
+    monkeypatch.setenv("FEDSTELLAR_DB_DIR", str(tmp_path / "db"))
+    monkeypatch.setenv("FEDSTELLAR_CONFIG_DIR", str(tmp_path / "config"))
+    monkeypatch.setenv("FEDSTELLAR_LOGS_DIR", str(tmp_path / "logs"))
+    monkeypatch.setenv("FEDSTELLAR_ADMIN_PASSWORD", "s3cret")
+    from p2pfl_amd.webserver import app as appmod
+    appmod = importlib.reload(appmod)
+    appmod.app.config.update(TESTING=True, config_dir=str(tmp_path / "config"), log_dir=str(tmp_path / "logs"))
+    os.makedirs(tmp_path / "config", exist_ok=True)
+    os.makedirs(tmp_path / "logs", exist_ok=True)
+    appmod.db.init_db()
+    return appmod, appmod.app.test_client(), tmp_path
+
+
+def _login(client, user="admin", pwd="s3cret"):
+    return client.post("/login", data={"user": user, "password": pwd})
+
+
+def test_login_logout_and_guards(web):
+    _, c, _ = web
+    assert c.get("/").status_code == 200
+    assert c.get("/scenario/").status_code == 401
+    assert _login(c, pwd="wrong").status_code == 401
+    assert _login(c).status_code == 302
+    assert c.get("/scenario/").status_code == 200
+    assert c.get("/scenario/deployment/").status_code == 200
+    assert c.get("/logout/").status_code == 302
+    assert c.get("/scenario/").status_code == 401
+    assert c.get("/nope").status_code == 404
+
+
+def test_admin_user_crud_and_notes(web):
+    appmod, c, _ = web
+    _login(c)
+    assert c.get("/admin/").status_code == 200
+    assert c.post("/add_user", data={"user": "alice", "password": "pw", "role": "user"}).status_code == 302
+    assert "ALICE" in appmod.db.list_users()
+    assert c.post("/add_user", data={"user": "alice", "password": "pw", "role": "user"}).status_code == 403
+    assert c.post("/add_user", data={"user": "a; DROP TABLE users", "password": "pw"}).status_code == 403
+    c.get("/logout/")
+    assert _login(c, "alice", "pw").status_code == 302
+    assert c.get("/admin/").status_code == 401
+    c.post("/write_note", data={"text_note_to_take": "hello"})
+    notes = appmod.db.read_note_from_db("alice")
+    assert len(notes) == 1 and notes[0][2] == "hello"
+    c.get("/logout/")
+    _login(c)
+    assert c.get(f"/delete_note/{notes[0][0]}").status_code == 401     # not the owner
+    assert c.get("/delete_user/alice/").status_code == 302
+    assert "ALICE" not in appmod.db.list_users() and appmod.db.read_note_from_db("alice") == []
+    assert c.get("/delete_user/admin/").status_code == 403
+
+
+def _participant(idx, scenario, port):
+    from p2pfl_amd.config.config import default_participant
+    p = default_participant()
+    p["scenario_args"].update(name=scenario, federation="DFL")
+    p["device_args"].update(idx=idx, uid=f"uid{idx}", role="aggregator")
+    p["network_args"].update(ip="127.0.0.1", port=port, neighbors=" ".join(f"127.0.0.1:{q}" for q in (46000, 46001) if q != port))
+    return p
+
+
+def test_node_update_and_monitoring_online_rule(web):
+    appmod, c, tmp = web
+    name = "fedstellar_DFL_test"
+    appmod.db.scenario_update_record(name, "now", "", "t", "d", "running", "")
+    os.makedirs(tmp / "config" / name)
+    for i in range(2):
+        r = c.post(f"/scenario/{name}/node/update", data=json.dumps(_participant(i, name, 46000 + i)),
+                   content_type="application/json")
+        assert r.status_code == 200 and r.get_json()["node_uid"] == f"uid{i}"
+    assert (tmp / "config" / name / "participant_1.json").exists()
+    assert c.post(f"/scenario/{name}/node/update", data="{}", content_type="application/json").status_code == 400
+    d = c.get(f"/api/scenario/{name}/monitoring").get_json()
+    assert d["scenario_status"] == "running" and [n["status"] for n in d["nodes_table"]] == [True, True]
+    assert d["nodes_table"][0]["neighbors"] == "127.0.0.1:46001"
+    # a node that reported > 20 s ago is offline
+    old = (datetime.datetime.now() - datetime.timedelta(seconds=60)).strftime("%Y-%m-%d %H:%M:%S.%f")
+    appmod.db.update_node_record("uid1", 1, "127.0.0.1", 46001, "aggregator", "127.0.0.1:46000", 0, 0, old, "DFL", name)
+    d = c.get(f"/api/scenario/{name}/monitoring").get_json()
+    assert [n["status"] for n in d["nodes_table"]] == [True, False]
+    assert c.get("/api/scenario/unknown/monitoring").status_code == 404
+    assert c.get("/api/scenario/..%2Fetc/monitoring").status_code in (400, 404)
+    # HTML page (renders the topology image from the reported neighbours)
+    assert c.get(f"/scenario/{name}/monitoring").status_code == 401
+    _login(c)
+    assert c.get(f"/scenario/{name}/monitoring").status_code == 200
+    img = c.get(f"/scenario/{name}/topology/image/")
+    assert img.status_code in (200, 404)
+    rows = c.get("/api/scenario/").get_json()
+    assert rows[0]["name"] == name and rows[0]["status"] == "running"
+
+
+def test_logs_statistics_and_download(web):
+    _, c, tmp = web
+    name = "scen"
+    ldir = tmp / "logs" / name
+    os.makedirs(ldir / "metrics" / "participant_0")
+    (ldir / "participant_0.log").write_text("\x1b[32mline <one>\x1b[0m\nline two\n")
+    (ldir / "metrics" / "participant_0" / "metrics.csv").write_text(
+        "time,step,name,value\n1.0,0,Test/Loss,2.3\n2.0,1,Test/Loss,1.1\n2.0,1,TestEpoch/Accuracy,0.8\n")
+    r = c.get(f"/scenario/{name}/node/0/infolog")
+    assert r.status_code == 200 and b"line &lt;one&gt;" in r.data and b"\x1b" not in r.data
+    assert c.get(f"/scenario/{name}/node/0/errorlog").status_code == 404
+    assert c.get(f"/scenario/{name}/node/0/other").status_code == 404
+    m = c.get(f"/api/scenario/{name}/statistics/").get_json()
+    assert m["participant_0"]["Test/Loss"] == [[0, 2.3], [1, 1.1]]
+    _login(c)
+    assert b"TestEpoch/Accuracy" in c.get(f"/scenario/{name}/statistics/").data
+    z = c.get(f"/scenario/{name}/statistics/download")
+    assert z.status_code == 200
+    assert zipfile.ZipFile(io.BytesIO(z.data)).namelist() == ["participant_0/metrics.csv"]
+
+
+def test_deployment_run_builds_scenario_and_calls_launcher(web, monkeypatch):
+    appmod, c, tmp = web
+    started = {}
+    monkeypatch.setattr(appmod.Controller, "start_nodes_cmd", lambda self, idx: started.update(mode="cmd", idx=idx, n=self.n_nodes))
+    monkeypatch.setattr(appmod.Controller, "start_nodes_batched", lambda self: started.update(mode="batched", n=self.n_nodes))
+    monkeypatch.setattr(appmod.Controller, "killdockers", staticmethod(lambda: None))
+    body = {"scenario_title": "T", "scenario_description": "D", "n_nodes": 3, "federation": "SDFL", "topology": "ring",
+            "matrix": None, "simulation": True, "docker": False, "rounds": 2, "epochs": 1, "dataset": "MNIST", "model": "MLP",
+            "accelerator": "cpu", "engine": "process",
+            "nodes": {str(i): {"id": i, "ip": "127.0.0.1", "ipdemo": "", "port": 47000 + i,
+                               "role": "aggregator" if i == 0 else "trainer", "start": i == 0} for i in range(3)}}
+    assert c.post("/scenario/deployment/run", data=json.dumps(body), content_type="application/json").status_code == 401
+    _login(c)
+    r = c.post("/scenario/deployment/run", data=json.dumps(body), content_type="application/json")
+    assert r.status_code == 200, r.data
+    name = r.get_json()["scenario_name"]
+    assert name.startswith("fedstellar_SDFL_") and started == {"mode": "cmd", "idx": 0, "n": 3}
+    cdir = tmp / "config" / name
+    assert (cdir / "controller.json").exists()
+    p1 = json.loads((cdir / "participant_1.json").read_text())
+    assert p1["scenario_args"]["rounds"] == 2 and p1["device_args"]["role"] == "trainer"
+    assert p1["network_args"]["port"] == 47001 and len(p1["network_args"]["neighbors"].split()) == 2      # ring
+    assert p1["scenario_args"]["name"] == name and p1["device_args"]["uid"]
+    assert appmod.db.get_running_scenario()[0] == name
+    # stop, re-run from the stored controller.json, remove
+    assert c.get(f"/scenario/{name}/stop").status_code == 302
+    assert appmod.db.get_running_scenario() is None
+    started.clear()
+    assert c.get(f"/scenario/{name}/deployment/reload").status_code == 302
+    assert started["n"] == 3 and appmod.db.get_running_scenario()[0] == name
+    assert c.get(f"/scenario/{name}/remove").status_code == 302
+    assert appmod.db.get_scenario_by_name(name) is None and not cdir.exists()

@@ -1,0 +1,567 @@
+// Stage-2 convolution (C_in = 32 -> C_out = 64, 5x5 or 3x3 "same", + ReLU + 2x2 max-pool) of the
+// MNIST / FEMNIST CNNs for gfx950, forward and data gradient.
+//
+// Design: "resident image, shifted reads". A block keeps the (zero-padded) input image of its
+// samples in LDS as channel-last bf16 -- [y][x][c], one pixel = one 64-B (fwd, 32 ch) or 128-B
+// (dgrad, 64 ch) run -- so the MFMA A fragment of output pixel p for filter tap (ky,kx) and channel
+// block c0 is ONE ds_read_b128 at  addr(p) + (ky*row + kx*pixel) + c0 : the im2col matrix is never
+// formed, not even in LDS, and every tap costs a constant address offset. The K loop walks the taps;
+// per tap the [C_out][C_in] weight slice (4 KB of a bf16, tap-major copy made once per step by
+// p2pfl_conv2_prep) is double-buffered through LDS.
+//
+//   fwd  : M = pool-ordered pre-pool pixels m = (window*4 + q); the four rows of a pool window are
+//          four consecutive accumulator registers of one lane -> bias + ReLU + max-pool + arg-max
+//          code in registers. 2 samples / block, 13 row tiles over 4 waves, both 32-col halves per wave.
+//   dgrad: image = pooled gradient routed to the arg-max pixel while staging (75 % zeros are never
+//          read from HBM), M = natural pixels of one sample, N = C_in, taps mirrored.
+//
+// LDS strides are padded so ds_read_b128 lane groups spread over the 16 slots of the 256-B bank row
+// (searched offline: fwd 1.6x, dgrad 1.07x average conflict factor; LDS has 2x headroom here).
+// Blocks of one client are mapped to one XCD so its weights stay in that XCD's L2.
+//
+// Reference layers: fedstellar/learning/pytorch/mnist/models/cnn.py:138-142,152-154 and
+// fedstellar/learning/pytorch/femnist/models/cnn.py:137-139,147-148.
+#include "common.h"
+
+namespace {
+
+constexpr int P1 = 14, P2 = 7, CELLS1 = 196, CELLS2 = 49;
+constexpr int CIN = 32, COUT = 64;
+
+__host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+__device__ __forceinline__ int mfma_row_(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+template <int KS>
+struct Geo {
+    static constexpr int PAD = KS / 2;
+    static constexpr int IW = P1 + 2 * PAD;
+    static constexpr int T = KS * KS;
+    // forward image: 64 B / pixel
+    static constexpr int XRS = IW * 64 + 16;
+    static constexpr int XSS = IW * XRS + (IW == 16 ? 32 : 0);
+    // gradient image: 128 B + 16 pad / pixel; row pad makes the 14-pixel row wrap look like +1 pixel
+    static constexpr int GPS = 144;
+    static constexpr int GRS = IW * GPS + 16 * ((((P1 - IW) * 9) % 16 + 16) % 16);
+    static constexpr int GSS = IW * GRS;
+};
+
+// block id -> (client, sub-block) with all sub-blocks of a client on one XCD (ids round-robin over 8 XCDs)
+__device__ __forceinline__ bool xcd_map(int per_client, int K, int& c, int& sub) {
+    const int i = blockIdx.x;
+    const int xcd = i & 7, j = i >> 3;
+    c = (j / per_client) * 8 + xcd;
+    sub = j % per_client;
+    return c < K;
+}
+
+// ---------------------------------------------------------------------------------------
+// weight prep: W[n][c][t] fp32 -> Wf[t][n][c] (fwd B operand) and Wd[t'][c][n] (dgrad B operand,
+// t' = mirrored tap) in bf16
+// ---------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256) void conv2_prep_kernel(const float* w, long w_cs, __bf16* wp, long wp_cs) {
+    constexpr int T = KS * KS;
+    const int c = blockIdx.y;
+    const float* src = w + c * w_cs;
+    __bf16* wf = wp + c * wp_cs;
+    __bf16* wd = wf + T * COUT * CIN;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < COUT * CIN * T; i += gridDim.x * 256) {
+        const int t = i % T, nc = i / T;
+        const int n = nc / CIN, ci = nc % CIN;
+        const __bf16 v = (__bf16)src[i];
+        wf[(t * COUT + n) * CIN + ci] = v;
+        wd[((T - 1 - t) * CIN + ci) * COUT + n] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------
+struct FwdArgs {
+    const float* a1;   long a1_cs;     // [K][B][32][196] fp32
+    const __bf16* wp;  long wp_cs;     // prepared weights
+    const float* bias; long b_cs;      // [K][64]
+    float* a2;         long a2_cs;     // [K][B][64][49]
+    uint8_t* code;     long c_cs;
+    int K, B;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void conv2_fwd_kernel(FwdArgs a) {
+    using G = Geo<KS>;
+    constexpr int S = 2;                       // samples per block
+    constexpr int NWIN = S * CELLS2;           // 98 pool windows
+    constexpr int NTILE = (NWIN + 7) / 8;      // 13 row tiles of 8 windows
+    constexpr int MT = (NTILE + 3) / 4;        // tiles per wave (4,3,3,3)
+    __shared__ __attribute__((aligned(16))) unsigned char ximg[S * G::XSS];
+    __shared__ __attribute__((aligned(16))) unsigned char wbuf[2][COUT * 80];
+
+    int c, sub;
+    if (!xcd_map(cdiv(a.B, S), a.K, c, sub)) return;
+    const int b0 = sub * S;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    // ---- stage the padded images (fp32 NCHW -> bf16 channel-last)
+    const float* a1 = a.a1 + c * a.a1_cs;
+    for (int task = tid; task < S * G::IW * G::IW * 4; task += 256) {
+        const int g = task & 3, pp = task >> 2;
+        const int s = pp / (G::IW * G::IW), rr = pp % (G::IW * G::IW);
+        const int Y = rr / G::IW, X = rr % G::IW;
+        const int y = Y - G::PAD, x = X - G::PAD;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
+        if (y >= 0 && y < P1 && x >= 0 && x < P1 && b0 + s < a.B) {
+            const float* src = a1 + ((size_t)(b0 + s) * CIN + 8 * g) * CELLS1 + y * P1 + x;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = src[i * CELLS1];
+        }
+        *reinterpret_cast<bf16x8*>(ximg + s * G::XSS + Y * G::XRS + X * 64 + g * 16) = pack_bf16x8(v);
+    }
+    const __bf16* wf = a.wp + c * a.wp_cs;
+    {
+        const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wf + tid * 8);
+        *reinterpret_cast<bf16x8*>(wbuf[0] + (tid >> 2) * 80 + (tid & 3) * 16) = w0;
+    }
+    __syncthreads();
+
+    // ---- per-lane image offsets of my row tiles
+    const int ntile = (NTILE - wave + 3) / 4;          // tiles wave, wave+4, ...
+    int abase[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int W = (wave + 4 * i) * 8 + (r >> 2);
+        if (W >= NWIN) W = 0;
+        const int q = r & 3, s = W / CELLS2, cell = W % CELLS2;
+        const int y = 2 * (cell / P2) + (q >> 1), x = 2 * (cell % P2) + (q & 1);
+        abase[i] = s * G::XSS + y * G::XRS + x * 64 + h * 16;
+    }
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    int ky = 0, kx = 0;
+#pragma unroll 1
+    for (int t = 0; t < G::T; ++t) {
+        bf16x8 wnext;
+        if (t + 1 < G::T) wnext = *reinterpret_cast<const bf16x8*>(wf + (t + 1) * COUT * CIN + tid * 8);
+        const unsigned char* wb = wbuf[t & 1] + r * 80 + h * 16;
+        const int toff = ky * G::XRS + kx * 64;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 bf0 = *reinterpret_cast<const bf16x8*>(wb + ks * 32);
+            const bf16x8 bf1 = *reinterpret_cast<const bf16x8*>(wb + 32 * 80 + ks * 32);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                if (i < ntile) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(ximg + abase[i] + toff + ks * 32);
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf0, acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf1, acc[i][1], 0, 0, 0);
+                }
+            }
+        }
+        if (t + 1 < G::T)
+            *reinterpret_cast<bf16x8*>(wbuf[(t + 1) & 1] + (tid >> 2) * 80 + (tid & 3) * 16) = wnext;
+        __syncthreads();
+        if (++kx == KS) { kx = 0; ++ky; }
+    }
+
+    // ---- epilogue: bias + ReLU + 2x2 max-pool + arg-max code, straight from the accumulators
+    const float* bias = a.bias + c * a.b_cs;
+    float* a2 = a.a2 + c * a.a2_cs;
+    uint8_t* code = a.code + c * a.c_cs;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        if (i >= ntile) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = j * 32 + r;
+            const float bv = bias[n];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int W = (wave + 4 * i) * 8 + 2 * g + h;
+                const int s = W / CELLS2, cell = W % CELLS2;
+                if (W >= NWIN || b0 + s >= a.B) continue;
+                float best = acc[i][j][4 * g]; int q = 0;
+                if (acc[i][j][4 * g + 1] > best) { best = acc[i][j][4 * g + 1]; q = 1; }
+                if (acc[i][j][4 * g + 2] > best) { best = acc[i][j][4 * g + 2]; q = 2; }
+                if (acc[i][j][4 * g + 3] > best) { best = acc[i][j][4 * g + 3]; q = 3; }
+                best += bv;
+                if (!(best > 0.f)) { best = 0.f; q = 4; }
+                const size_t o = ((size_t)(b0 + s) * COUT + n) * CELLS2 + cell;
+                a2[o] = best;
+                code[o] = (uint8_t)q;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// data gradient
+// ---------------------------------------------------------------------------------------
+struct DgradArgs {
+    const float* g;    long g_cs;      // da2 [K][B][64][49]
+    const uint8_t* code; long c_cs;
+    const __bf16* wp;  long wp_cs;
+    float* da1;        long da1_cs;    // [K][B][32][196]
+    int K, B;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void conv2_dgrad_kernel(DgradArgs a) {
+    using G = Geo<KS>;
+    constexpr int NTILE = (CELLS1 + 31) / 32;   // 7 row tiles of 32 pixels
+    constexpr int MT = (NTILE + 3) / 4;         // (2,2,2,1)
+    constexpr int WRS = 144;                    // LDS row of the weight slice: 64 n bf16 + 16 B pad
+    __shared__ __attribute__((aligned(16))) unsigned char gimg[G::GSS];
+    __shared__ __attribute__((aligned(16))) unsigned char wbuf[2][CIN * WRS];
+
+    int c, b;
+    if (!xcd_map(a.B, a.K, c, b)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    // ---- zero the image (halo + pixels of dead windows), then route the pooled gradient
+    for (int i = tid; i < G::GSS / 16; i += 256)
+        *reinterpret_cast<float4*>(gimg + i * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    const __bf16* wd = a.wp + c * a.wp_cs + G::T * COUT * CIN;
+    {
+        const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wd + tid * 8);
+        *reinterpret_cast<bf16x8*>(wbuf[0] + (tid >> 3) * WRS + (tid & 7) * 16) = w0;
+    }
+    __syncthreads();
+    const float* gsrc = a.g + c * a.g_cs + (size_t)b * COUT * CELLS2;
+    const uint8_t* csrc = a.code + c * a.c_cs + (size_t)b * COUT * CELLS2;
+    for (int task = tid; task < CELLS2 * 8; task += 256) {
+        const int cg = task / CELLS2, cell = task % CELLS2;
+        float gv[8]; int qc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            gv[i] = gsrc[(cg * 8 + i) * CELLS2 + cell];
+            qc[i] = csrc[(cg * 8 + i) * CELLS2 + cell];
+        }
+        const int Y = 2 * (cell / P2) + G::PAD, X = 2 * (cell % P2) + G::PAD;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (qc[i] == q) ? gv[i] : 0.f;
+            *reinterpret_cast<bf16x8*>(gimg + (Y + (q >> 1)) * G::GRS + (X + (q & 1)) * G::GPS + cg * 16) =
+                pack_bf16x8(v);
+        }
+    }
+    __syncthreads();
+
+    const int ntile = (NTILE - wave + 3) / 4;
+    int abase[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int p = (wave + 4 * i) * 32 + r;
+        if (p >= CELLS1) p = 0;
+        abase[i] = (p / P1) * G::GRS + (p % P1) * G::GPS + h * 16;
+    }
+    f32x16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    int ky = 0, kx = 0;   // mirrored tap index: image offset (ky,kx), weights of tap (KS-1-ky, KS-1-kx)
+#pragma unroll 1
+    for (int t = 0; t < G::T; ++t) {
+        bf16x8 wnext;
+        if (t + 1 < G::T) wnext = *reinterpret_cast<const bf16x8*>(wd + (t + 1) * COUT * CIN + tid * 8);
+        const unsigned char* wb = wbuf[t & 1] + r * WRS + h * 16;
+        const int toff = ky * G::GRS + kx * G::GPS;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(wb + ks * 32);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                if (i < ntile) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(gimg + abase[i] + toff + ks * 32);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[i], 0, 0, 0);
+                }
+            }
+        }
+        if (t + 1 < G::T)
+            *reinterpret_cast<bf16x8*>(wbuf[(t + 1) & 1] + (tid >> 3) * WRS + (tid & 7) * 16) = wnext;
+        __syncthreads();
+        if (++kx == KS) { kx = 0; ++ky; }
+    }
+
+    // ---- epilogue: lane = input channel, registers 4g..4g+3 = four consecutive pixels -> float4
+    float* dst = a.da1 + c * a.da1_cs + ((size_t)b * CIN + r) * CELLS1;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        if (i >= ntile) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int p = (wave + 4 * i) * 32 + 8 * g + 4 * h;
+            if (p < CELLS1)
+                *reinterpret_cast<float4*>(dst + p) =
+                    make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// weight gradient:  dW[n][c][t] = sum_{b,p} G[b][p][n] * X[b][p + t][c],   db[n] = sum G[b][p][n]
+//
+// GEMM per tap: M = C_out (2 row tiles), N = C_in (1 tile), K = pixels. Both operands need the pixel
+// index along K while the LDS images are channel-last, so fragments are fetched with gfx950's
+// transposing read ds_read_b64_tr_b16: one read hands every lane 4 consecutive pixels of its own
+// channel, and a tap is again just a constant address offset on the X image.
+// A block owns (client, 1/NP of the taps) and walks all samples of that client, so its accumulators
+// are the final gradient: plain stores, no atomics (device-scope fp32 atomics across XCDs measured
+// 20x slower than the whole GEMM), bitwise reproducible. 8 waves = 4 tap groups x 2 row tiles; a wave
+// shares its G fragment across its taps; the bias gradient rides along as one more MFMA against a
+// ones fragment. NP is picked by the launcher so that K * NP blocks fill the CUs.
+// Image strides: 4 consecutive pixels fall into the four 64-B quarters of the 256-B bank row
+// (X: 64-B pixels, row stride = 128 mod 256 so the 14-pixel row wrap keeps the pattern; G: 192-B
+// pixels), i.e. the transposed reads are bank-conflict-free.
+// ---------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* lds0, const unsigned char* lds1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)lds0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)lds1);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+struct WgradArgs {
+    const float* g;    long g_cs;      // da2 [K][B][64][49]
+    const uint8_t* code; long c_cs;
+    const float* a1;   long a1_cs;     // [K][B][32][196]
+    float* dw;         long dw_cs;     // [K][64][32*T]
+    float* db;         long db_cs;     // [K][64]
+    int K, B;
+};
+
+template <int KS, int NP>
+__global__ __launch_bounds__(512, 2) void conv2_wgrad_kernel(WgradArgs a) {
+    using G = Geo<KS>;
+    constexpr int T = G::T;
+    constexpr int NTAP = ((T + NP - 1) / NP + 3) / 4;    // most taps per wave
+    constexpr int XRS = G::IW * 64 + ((((P1 - G::IW) * 64) % 256) + 256) % 256;
+    constexpr int XROWS = G::IW + 1;                     // +1 zero row: K padding (pixels 196..207) reads it
+    constexpr int GPS = 192;
+    constexpr int KSTEPS = (CELLS1 + 15) / 16;           // 13
+    constexpr int NPIX = KSTEPS * 16;                    // 208 (last 12 stay zero)
+    __shared__ __attribute__((aligned(16))) unsigned char ximg[XROWS * XRS];
+    __shared__ __attribute__((aligned(16))) unsigned char gimg[NPIX * GPS];
+
+    int c, tp;
+    if (!xcd_map(NP, a.K, c, tp)) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tg = wave >> 1, mt = wave & 1;
+    // taps of this block [p0, p1) split over the four tap groups; (part 0, group 0) also owns the bias
+    const int p0 = tp * T / NP, np = (tp + 1) * T / NP - p0;
+    const int t_begin = p0 + tg * np / 4;
+    const int ntap = p0 + (tg + 1) * np / 4 - t_begin;
+    const bool do_bias = (tp == 0 && tg == 0);
+    int toff[NTAP];
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j) {
+        const int t = min(t_begin + j, T - 1);
+        toff[j] = (t / KS) * XRS + (t % KS) * 64;
+    }
+
+    for (int i = tid; i < XROWS * XRS / 16; i += 512)
+        *reinterpret_cast<float4*>(ximg + i * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < NPIX * GPS / 16; i += 512)
+        *reinterpret_cast<float4*>(gimg + i * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // lane roles in the transposed reads
+    const int grp = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+    const int p_lane = (grp >> 1) * 8 + q;                          // pixel of this lane within a k-step (+4h)
+    const int ch_off = ((grp & 1) * 16 + 4 * pq) * 2;                // byte offset of its 4 channels
+    const int g_lane = mt * 64 + ch_off;
+
+    // staging roles (global -> registers -> LDS)
+    float xv[2][8]; float gv[8]; int qc[8];
+    auto prefetch = [&](int b) {
+        const float* a1 = a.a1 + c * a.a1_cs + (size_t)b * CIN * CELLS1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int task = tid + 512 * u;
+            if (task < CELLS1 * 4) {
+                const float* src = a1 + (task & 3) * 8 * CELLS1 + (task >> 2);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xv[u][i] = src[i * CELLS1];
+            }
+        }
+        if (tid < CELLS2 * 8) {
+            const int cg = tid / CELLS2, cell = tid % CELLS2;
+            const float* gs = a.g + c * a.g_cs + ((size_t)b * COUT + cg * 8) * CELLS2 + cell;
+            const uint8_t* cs = a.code + c * a.c_cs + ((size_t)b * COUT + cg * 8) * CELLS2 + cell;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { gv[i] = gs[i * CELLS2]; qc[i] = cs[i * CELLS2]; }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int task = tid + 512 * u;
+            if (task < CELLS1 * 4) {
+                const int p = task >> 2;
+                *reinterpret_cast<bf16x8*>(ximg + (p / P1 + G::PAD) * XRS + (p % P1 + G::PAD) * 64 + (task & 3) * 16) =
+                    pack_bf16x8(xv[u]);
+            }
+        }
+        if (tid < CELLS2 * 8) {
+            const int cg = tid / CELLS2, cell = tid % CELLS2;
+            const int p00 = 2 * (cell / P2) * P1 + 2 * (cell % P2);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = (qc[i] == qq) ? gv[i] : 0.f;
+                *reinterpret_cast<bf16x8*>(gimg + (p00 + (qq >> 1) * P1 + (qq & 1)) * GPS + cg * 16) = pack_bf16x8(v);
+            }
+        }
+    };
+
+    f32x16 acc[NTAP], accb;
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int j = 0; j < NTAP; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accb[e] = 0.f;
+    };
+    zero_acc();
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+    prefetch(0);
+    for (int item = 0; item < a.B; ++item) {
+        __syncthreads();            // everyone finished reading the previous images (or zero-filling)
+        commit();
+        __syncthreads();
+        if (item + 1 < a.B) prefetch(item + 1);
+
+#pragma unroll 1
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int pa = ks * 16 + p_lane, pb = pa + 4;
+            const unsigned char* ga = gimg + pa * GPS + g_lane;
+            const bf16x8 af = tr_frag(ga, ga + 4 * GPS);
+            const unsigned char* xa = ximg + (pa / P1) * XRS + (pa % P1) * 64 + ch_off;
+            const unsigned char* xb = ximg + (pb / P1) * XRS + (pb % P1) * 64 + ch_off;
+#pragma unroll
+            for (int j = 0; j < NTAP; ++j) {
+                if (j < ntap) {
+                    const bf16x8 bfr = tr_frag(xa + toff[j], xb + toff[j]);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[j], 0, 0, 0);
+                }
+            }
+            if (do_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, accb, 0, 0, 0);
+        }
+    }
+
+    float* dw = a.dw + c * a.dw_cs;
+    const int ci = lane & 31;
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j) {
+        if (j < ntap) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = mt * 32 + mfma_row_(e, lane);
+                dw[((size_t)n * CIN + ci) * T + t_begin + j] = acc[j][e];
+            }
+        }
+    }
+    if (do_bias && ci == 0) {
+        float* db = a.db + c * a.db_cs;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) db[mt * 32 + mfma_row_(e, lane)] = accb[e];
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+// wp: per client 2 * KS*KS * 64 * 32 bf16 (forward copy, then mirrored data-gradient copy)
+P2PFL_API int p2pfl_conv2_prep(const float* w, long w_cs, void* wp, long wp_cs, int K, int CIN_, int COUT_,
+                               int KS, hipStream_t stream) {
+    if (K <= 0 || CIN_ != CIN || COUT_ != COUT) return -1;
+    if (wp_cs < 2L * KS * KS * COUT * CIN || (wp_cs & 7) || ((uintptr_t)wp & 15)) return -2;
+    dim3 grid(cdiv(COUT * CIN * KS * KS, 256 * 4), K);
+    if (KS == 5) hipLaunchKernelGGL(conv2_prep_kernel<5>, grid, dim3(256), 0, stream, w, w_cs, (__bf16*)wp, wp_cs);
+    else if (KS == 3) hipLaunchKernelGGL(conv2_prep_kernel<3>, grid, dim3(256), 0, stream, w, w_cs, (__bf16*)wp, wp_cs);
+    else return -3;
+    P2PFL_RETURN_LAST_ERROR();
+}
+
+P2PFL_API int p2pfl_conv2_fwd(const float* a1, long a1_cs, const void* wp, long wp_cs, const float* bias,
+                              long b_cs, float* a2, long a2_cs, uint8_t* code, long c_cs, int K, int B,
+                              int CIN_, int COUT_, int KS, hipStream_t stream) {
+    if (K <= 0 || B <= 0 || CIN_ != CIN || COUT_ != COUT) return -1;
+    if ((wp_cs & 7) || ((uintptr_t)wp & 15)) return -2;
+    FwdArgs a{a1, a1_cs, (const __bf16*)wp, wp_cs, bias, b_cs, a2, a2_cs, code, c_cs, K, B};
+    dim3 grid(cdiv(K, 8) * 8 * cdiv(B, 2));
+    if (KS == 5) hipLaunchKernelGGL(conv2_fwd_kernel<5>, grid, dim3(256), 0, stream, a);
+    else if (KS == 3) hipLaunchKernelGGL(conv2_fwd_kernel<3>, grid, dim3(256), 0, stream, a);
+    else return -3;
+    P2PFL_RETURN_LAST_ERROR();
+}
+
+P2PFL_API int p2pfl_conv2_dgrad(const float* g, long g_cs, const uint8_t* code, long c_cs, const void* wp,
+                                long wp_cs, float* da1, long da1_cs, int K, int B, int CIN_, int COUT_,
+                                int KS, hipStream_t stream) {
+    if (K <= 0 || B <= 0 || CIN_ != CIN || COUT_ != COUT) return -1;
+    if ((wp_cs & 7) || ((uintptr_t)wp & 15) || (da1_cs & 3) || ((uintptr_t)da1 & 15)) return -2;
+    DgradArgs a{g, g_cs, code, c_cs, (const __bf16*)wp, wp_cs, da1, da1_cs, K, B};
+    dim3 grid(cdiv(K, 8) * 8 * B);
+    if (KS == 5) hipLaunchKernelGGL(conv2_dgrad_kernel<5>, grid, dim3(256), 0, stream, a);
+    else if (KS == 3) hipLaunchKernelGGL(conv2_dgrad_kernel<3>, grid, dim3(256), 0, stream, a);
+    else return -3;
+    P2PFL_RETURN_LAST_ERROR();
+}
+
+static int num_cus() {
+    static int n = 0;
+    if (n <= 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+    }
+    return n;
+}
+
+template <int KS>
+static void launch_wgrad(const WgradArgs& a, int np, hipStream_t stream) {
+    const dim3 block(512);
+    if (np == 1) hipLaunchKernelGGL((conv2_wgrad_kernel<KS, 1>), dim3(cdiv(a.K, 8) * 8), block, 0, stream, a);
+    else if (np == 2) hipLaunchKernelGGL((conv2_wgrad_kernel<KS, 2>), dim3(cdiv(a.K, 8) * 8 * 2), block, 0, stream, a);
+    else hipLaunchKernelGGL((conv2_wgrad_kernel<KS, 5>), dim3(cdiv(a.K, 8) * 8 * 5), block, 0, stream, a);
+}
+
+P2PFL_API int p2pfl_conv2_wgrad(const float* g, long g_cs, const uint8_t* code, long c_cs, const float* a1,
+                                long a1_cs, float* dw, long dw_cs, float* db, long db_cs, int K, int B,
+                                int CIN_, int COUT_, int KS, hipStream_t stream) {
+    if (K <= 0 || B <= 0 || CIN_ != CIN || COUT_ != COUT) return -1;
+    const int cus = num_cus();
+    const int np = K >= cus ? 1 : (2 * K >= (cus * 3) / 4 ? 2 : 5);   // K * np blocks should fill the CUs
+    WgradArgs a{g, g_cs, code, c_cs, a1, a1_cs, dw, dw_cs, db, db_cs, K, B};
+    if (KS == 5) launch_wgrad<5>(a, np, stream);
+    else if (KS == 3) launch_wgrad<3>(a, np, stream);
+    else return -3;
+    P2PFL_RETURN_LAST_ERROR();
+}

@@ -56,6 +56,7 @@ class _Sig:
     p2pfl_linear_wgrad_adam = [P, L, P, L, P, P, P, L, P, P, P, L, I, I, I, I, F, F, F, F, F, I, P, P]
     p2pfl_conv1_fwd = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, P]
     p2pfl_conv1_wgrad = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, P]
+    p2pfl_conv2_prep = [P, L, P, L, I, I, I, I, P]
     p2pfl_conv2_fwd = [P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, P]
     p2pfl_conv2_wgrad = [P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, P]
     p2pfl_conv2_dgrad = [P, L, P, L, P, L, P, L, I, I, I, I, I, P]
@@ -167,20 +168,39 @@ def conv1_wgrad(g, code, data, sidx, dw, db, ks: int) -> None:
          "conv1_wgrad")
 
 
-def conv2_fwd(a1, w, bias, a2, code, ks: int) -> None:
+def conv2_prep_alloc(K: int, ks: int, device) -> torch.Tensor:
+    """Workspace of :func:`conv2_prep`: per client a tap-major bf16 copy of the stage-2 weights for the
+    forward pass followed by the mirrored, transposed copy for the data gradient."""
+    return torch.empty(K, 2 * ks * ks * 64 * 32, dtype=torch.bfloat16, device=device)
+
+
+def conv2_prep(w, wprep, ks: int) -> None:
+    """w [K,Cout=64,Cin*ks*ks] fp32 -> wprep (see conv2_prep_alloc). Run once per weight update."""
+    K, Cout = w.shape[0], w.shape[1]
+    Cin = w.shape[2] // (ks * ks)
+    (wp, ws), (pp, ps) = _pc(w), _pc(wprep, torch.bfloat16)
+    _chk(load().p2pfl_conv2_prep(wp, ws, pp, ps, K, Cin, Cout, ks, _stream()), "conv2_prep")
+
+
+def conv2_fwd(a1, w, bias, a2, code, ks: int, wprep=None) -> None:
     """Stage-2 conv(Cin->Cout, ks x ks, same) + ReLU + 2x2 maxpool on the matrix cores.
 
     a1 [K,B,Cin,196], w [K,Cout,Cin*ks*ks], bias [K,Cout], a2 [K,B,Cout,49], code uint8 like a2.
+    ``wprep``: workspace already filled by :func:`conv2_prep` for these weights (else made here).
     """
     K, B, Cin = a1.shape[0], a1.shape[1], a1.shape[2]
     Cout = w.shape[1]
-    (ap, as_), (wp, ws), (bp, bs), (op, os_) = _pc(a1), _pc(w), _pc(bias), _pc(a2)
+    if wprep is None:
+        wprep = conv2_prep_alloc(K, ks, a1.device)
+        conv2_prep(w, wprep, ks)
+    (ap, as_), (pp, ps), (bp, bs), (op, os_) = _pc(a1), _pc(wprep, torch.bfloat16), _pc(bias), _pc(a2)
     cp, cs = _pc(code, torch.uint8)
-    _chk(load().p2pfl_conv2_fwd(ap, as_, wp, ws, bp, bs, op, os_, cp, cs, K, B, Cin, Cout, ks, _stream()),
+    _chk(load().p2pfl_conv2_fwd(ap, as_, pp, ps, bp, bs, op, os_, cp, cs, K, B, Cin, Cout, ks, _stream()),
          "conv2_fwd")
 
 
 def conv2_wgrad(g, code, a1, dw, db, ks: int) -> None:
+    """Stage-2 weight/bias gradient: dw [K,Cout,Cin*ks*ks], db [K,Cout] (overwritten)."""
     K, B, Cout = g.shape[0], g.shape[1], g.shape[2]
     Cin = a1.shape[2]
     (gp, gs), (ap, as_), (wp, ws), (bp, bs) = _pc(g), _pc(a1), _pc(dw), _pc(db)
@@ -189,12 +209,15 @@ def conv2_wgrad(g, code, a1, dw, db, ks: int) -> None:
          "conv2_wgrad")
 
 
-def conv2_dgrad(g, code, w, da1, ks: int) -> None:
+def conv2_dgrad(g, code, w, da1, ks: int, wprep=None) -> None:
     K, B, Cout = g.shape[0], g.shape[1], g.shape[2]
     Cin = da1.shape[2]
-    (gp, gs), (wp, ws), (dp, ds) = _pc(g), _pc(w), _pc(da1)
+    if wprep is None:
+        wprep = conv2_prep_alloc(K, ks, g.device)
+        conv2_prep(w, wprep, ks)
+    (gp, gs), (pp, ps), (dp, ds) = _pc(g), _pc(wprep, torch.bfloat16), _pc(da1)
     cp, cs = _pc(code, torch.uint8)
-    _chk(load().p2pfl_conv2_dgrad(gp, gs, cp, cs, wp, ws, dp, ds, K, B, Cin, Cout, ks, _stream()), "conv2_dgrad")
+    _chk(load().p2pfl_conv2_dgrad(gp, gs, cp, cs, pp, ps, dp, ds, K, B, Cin, Cout, ks, _stream()), "conv2_dgrad")
 
 
 # ----------------------------------------------------------------------------- loss / misc

@@ -1,0 +1,136 @@
+"""Topology -> collective planner.
+
+The reference moves models with a per-node TCP gossip (fedstellar/node.py:692-809): O(N^2) payloads
+per round on a fully connected federation. Here the nodes of a scenario are split into contiguous
+blocks, one block per GPU, and the *fixed point* of that gossip (every aggregating node ends the
+round holding the weighted mean of its train set, see ``runtime/aggregation.py``) is mapped onto
+the cheapest RCCL pattern for the federation graph:
+
+``allreduce``  every aggregating node shares ONE contributor set (fully connected DFL, CFL star,
+               SDFL with a single leader): each GPU reduces its local contributors to one [P] row,
+               one all-reduce(sum) combines the partials; payload per GPU is P*4 bytes whatever N is.
+``rows``       contributor sets differ (ring, random-k, custom matrices): one variable-split
+               all-to-all moves exactly the rows a peer needs (a row crosses a link at most once per
+               destination GPU even when many nodes there need it); the grouped reduce kernel then
+               reads local rows in place and remote rows from the staging buffer.
+
+Everything in this module is pure Python over node ids, so the 8-GPU schedules are checked
+structurally on the CPU (tests/test_parallel_planner.py): what rank a sends to rank b is exactly what
+b expects from a, in the same order.
+
+xGMI is a point-to-point mesh (7 links x ~153 GB/s per GPU). :func:`estimate_exchange_seconds`
+prices a plan per *link*, which is what bounds both patterns, and is used by the bench / docs to
+reason about scaling; it is not a tuning knob.
+"""
+from __future__ import annotations
+
+import hashlib
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+XGMI_LINK_BYTES_PER_S = 153e9      # per direction, per link (MI355X: 7 links per GPU)
+XGMI_LINKS = 7
+
+
+def partition_nodes(n_nodes: int, world: int) -> List[range]:
+    """Contiguous, balanced blocks of node ids per rank."""
+    base, rem = divmod(n_nodes, world)
+    out, start = [], 0
+    for r in range(world):
+        cnt = base + (1 if r < rem else 0)
+        out.append(range(start, start + cnt))
+        start += cnt
+    return out
+
+
+def owner_of(n_nodes: int, world: int) -> np.ndarray:
+    owner = np.zeros(n_nodes, dtype=np.int64)
+    for r, blk in enumerate(partition_nodes(n_nodes, world)):
+        owner[list(blk)] = r
+    return owner
+
+
+def link_key(scenario: str, a: int, b: int) -> bytes:
+    """Deterministic 16-byte AES key of the (unordered) rank link a<->b."""
+    lo, hi = (a, b) if a <= b else (b, a)
+    return hashlib.sha256(f"{scenario}|link|{lo}|{hi}".encode()).digest()[:16]
+
+
+@dataclass
+class ExchangePlan:
+    """What one rank does in the exchange phase of a round."""
+    mode: str                                     # "allreduce" | "rows"
+    # allreduce mode
+    local_sources: List[int] = field(default_factory=list)      # contributor node ids owned by this rank
+    local_weights: List[float] = field(default_factory=list)    # already divided by the global weight sum
+    local_dests: List[int] = field(default_factory=list)        # node ids on this rank that take the result
+    # rows mode
+    send_lists: List[List[int]] = field(default_factory=list)   # per peer rank: node ids whose rows we send
+    recv_lists: List[List[int]] = field(default_factory=list)   # per peer rank: node ids whose rows we receive
+    row_of: Dict[int, int] = field(default_factory=dict)        # node id -> row of the source pool (local | staged)
+    groups: List[tuple] = field(default_factory=list)           # (contributor ids, weights, local destination rows)
+    n_recv: int = 0
+
+    def rows_sent(self) -> int:
+        return sum(len(l) for l in self.send_lists)
+
+
+def plan_exchange(train_sets: Dict[int, Sequence[int]], adopt: Dict[int, int], owner: np.ndarray,
+                  weights: Sequence[float], rank: int, world: int, local: range) -> ExchangePlan:
+    """Exchange plan of ``rank`` for one round structure.
+
+    train_sets: aggregating node -> contributor node ids; adopt: waiting node -> aggregating node.
+    """
+    local_set = set(local)
+    lo = local.start
+    keys = {tuple(ts) for ts in train_sets.values()}
+    if world > 1 and len(keys) == 1:
+        contributors = list(next(iter(keys)))
+        dests = sorted(set(train_sets) | set(adopt))
+        tot = float(sum(weights[j] for j in contributors))
+        loc_src = [j for j in contributors if j in local_set]
+        return ExchangePlan("allreduce", local_sources=loc_src, local_weights=[weights[j] / tot for j in loc_src],
+                            local_dests=[d for d in dests if d in local_set])
+    adopters: Dict[int, List[int]] = {}
+    for w, a in adopt.items():
+        adopters.setdefault(a, []).append(w)
+    needed_by: List[set] = [set() for _ in range(world)]        # needed_by[r] = node rows rank r must receive
+    for i, ts in train_sets.items():
+        # the result of i is needed on owner(i) and on the owners of the nodes adopting it
+        for r in {int(owner[i])} | {int(owner[w]) for w in adopters.get(i, [])}:
+            needed_by[r].update(j for j in ts if owner[j] != r)
+    send_lists = [sorted(j for j in needed_by[r] if owner[j] == rank) if r != rank else [] for r in range(world)]
+    recv_lists = [sorted(j for j in needed_by[rank] if owner[j] == r) if r != rank else [] for r in range(world)]
+    row_of = {j: j - lo for j in local}
+    pos = len(local)
+    for r in range(world):
+        for j in recv_lists[r]:
+            row_of[j] = pos
+            pos += 1
+    merged: Dict[tuple, List[int]] = {}
+    for i, ts in train_sets.items():
+        dsts = ([i] if i in local_set else []) + [w for w in adopters.get(i, []) if w in local_set]
+        if dsts:
+            merged.setdefault(tuple(ts), []).extend(d - lo for d in dsts)
+    groups = [([row_of[j] for j in key], [weights[j] for j in key], dsts) for key, dsts in merged.items()]
+    return ExchangePlan("rows", send_lists=send_lists, recv_lists=recv_lists, row_of=row_of, groups=groups,
+                        n_recv=pos - len(local))
+
+
+def estimate_exchange_seconds(plan: ExchangePlan, row_bytes: int, world: int,
+                              link_bytes_per_s: float = XGMI_LINK_BYTES_PER_S) -> float:
+    """Per-link lower bound of the exchange time on the xGMI mesh.
+
+    allreduce: direct reduce-scatter + all-gather over the mesh moves 2*(world-1)/world of a row per
+    GPU, spread over ``min(world-1, 7)`` links. rows: every peer pair has its own link, so the bound is
+    the largest single (src,dst) transfer.
+    """
+    if world <= 1:
+        return 0.0
+    if plan.mode == "allreduce":
+        links = min(world - 1, XGMI_LINKS)
+        return 2.0 * (world - 1) / world * row_bytes / (links * link_bytes_per_s)
+    worst = max([len(l) for l in plan.send_lists] + [len(l) for l in plan.recv_lists] + [0])
+    return worst * row_bytes / link_bytes_per_s

@@ -257,6 +257,9 @@ class HipEngine(ShardEngine):
             self.act.append(torch.zeros(shp, device=dev))
             self.dact.append(torch.zeros(shp, device=dev))
             self.code.append(torch.zeros(shp, dtype=torch.uint8, device=dev) if l.kind != "linear" else None)
+        # tap-major bf16 weight copies of the stage-2 convolutions (refreshed at every forward pass)
+        self.wprep = {i: hip.conv2_prep_alloc(K, l.ksize, dev) for i, l in enumerate(self.spec.layers)
+                      if l.kind == "conv2pool"}
         self.xin = torch.zeros(K, B, 784, device=dev) if self.spec.layers[0].kind == "linear" else None
         self.karange = torch.arange(K, device=dev).unsqueeze(1)
         self._nv_cache: Dict[int, torch.Tensor] = {}
@@ -311,7 +314,8 @@ class HipEngine(ShardEngine):
             if l.kind == "conv1pool":
                 hip.conv1_fwd(data, sidx, W, b, self.act[i], self.code[i], l.ksize)
             elif l.kind == "conv2pool":
-                hip.conv2_fwd(x, W, b, self.act[i], self.code[i], l.ksize)
+                hip.conv2_prep(W, self.wprep[i], l.ksize)
+                hip.conv2_fwd(x, W, b, self.act[i], self.code[i], l.ksize, wprep=self.wprep[i])
             else:
                 if x is None:
                     if sidx is None:
@@ -359,7 +363,7 @@ class HipEngine(ShardEngine):
                     dy = dy_next
             elif l.kind == "conv2pool":
                 hip.conv2_wgrad(dy, self.code[i], self.act[i - 1], gW, gb, l.ksize)
-                hip.conv2_dgrad(dy, self.code[i], W, self.dact[i - 1], l.ksize)
+                hip.conv2_dgrad(dy, self.code[i], W, self.dact[i - 1], l.ksize, wprep=self.wprep[i])
                 dy = self.dact[i - 1]
             else:  # conv1pool (first layer: no data gradient)
                 hip.conv1_wgrad(dy, self.code[i], data, sidx, gW, gb, l.ksize)

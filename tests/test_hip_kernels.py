@@ -152,10 +152,10 @@ def test_conv1_wgrad(ks):
         assert rel_err(db[k], dpre[k].sum(dim=(0, 2, 3))) < 2e-2
 
 
-@pytest.mark.parametrize("ks,B", [(5, 32), (3, 32), (5, 9)])
-def test_conv2_fwd(ks, B):
+@pytest.mark.parametrize("ks,B,K", [(5, 32, 2), (3, 32, 2), (5, 9, 3), (5, 32, 11), (3, 7, 9)])
+def test_conv2_fwd(ks, B, K):
     h = hip()
-    K, Cin, Cout = 2, 32, 64
+    Cin, Cout = 32, 64
     a1 = torch.randn(K, B, Cin, 196, device=DEV).relu()
     w = slab_view(K, (Cout, Cin * ks * ks)) * 0.05
     b = slab_view(K, (Cout,)) * 0.1
@@ -169,10 +169,10 @@ def test_conv2_fwd(ks, B):
         assert ((a2[k] == 0) == (code[k] == 4)).all()
 
 
-@pytest.mark.parametrize("ks,B", [(5, 32), (3, 32), (5, 9)])
-def test_conv2_wgrad_dgrad(ks, B):
+@pytest.mark.parametrize("ks,B,K", [(5, 32, 2), (3, 32, 2), (5, 9, 3), (5, 32, 11), (3, 7, 9)])
+def test_conv2_wgrad_dgrad(ks, B, K):
     h = hip()
-    K, Cin, Cout = 2, 32, 64
+    Cin, Cout = 32, 64
     a1 = torch.randn(K, B, Cin, 196, device=DEV).relu()
     w = slab_view(K, (Cout, Cin * ks * ks)) * 0.05
     g = torch.randn(K, B, Cout, 49, device=DEV)

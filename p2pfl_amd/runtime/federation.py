@@ -36,6 +36,8 @@ import torch
 import torch.distributed as dist
 
 from ..models.specs import ModelSpec
+from ..parallel.collectives import DeviceExchange
+from ..parallel.planner import link_key, partition_nodes, plan_exchange  # noqa: F401  (re-exported)
 from ..role import Role, default_roles
 from .aggregation import AggregationPlan, build_plan, plan_from_train_sets, run_plan
 from .engine import ShardEngine, make_engine
@@ -51,23 +53,6 @@ class RoundReport:
     test_accuracy: Optional[torch.Tensor] = None
     train_loss: Optional[torch.Tensor] = None
     exchanged_rows: int = 0
-
-
-def partition_nodes(n_nodes: int, world: int) -> List[range]:
-    """Contiguous, balanced blocks of node ids per rank."""
-    base, rem = divmod(n_nodes, world)
-    out, start = [], 0
-    for r in range(world):
-        cnt = base + (1 if r < rem else 0)
-        out.append(range(start, start + cnt))
-        start += cnt
-    return out
-
-
-def link_key(scenario: str, a: int, b: int) -> bytes:
-    """Deterministic 16-byte AES key of the (unordered) rank link a<->b."""
-    lo, hi = (a, b) if a <= b else (b, a)
-    return hashlib.sha256(f"{scenario}|link|{lo}|{hi}".encode()).digest()[:16]
 
 
 class BatchedFederation:
@@ -99,9 +84,9 @@ class BatchedFederation:
         self.weights = np.zeros(self.N, dtype=np.float64)       # training samples per node
         self.round = 0
         self.rng = random.Random(seed)                            # shared by all ranks (same seed)
+        self.comm = DeviceExchange(rank, world_size, process_group, self.device, encrypt, scenario)
         self.staging: Optional[torch.Tensor] = None
         self._plan_cache: Dict[bytes, tuple] = {}
-        self._rk_cache: Dict[tuple, torch.Tensor] = {}
         self.faults: Dict[int, List[tuple]] = {}                  # round -> [(action, node)]
         self.reports: List[RoundReport] = []
 
@@ -156,125 +141,22 @@ class BatchedFederation:
         return h.digest()
 
     def _build_exchange(self, train_sets, adopt):
-        """Who needs which remote rows. Returns (send_lists, recv_lists, row_of, plan, mode)."""
-        me = self.rank
-        local_set = set(self.local)
-        lo = self.local.start
-        needed_by: List[set] = [set() for _ in range(self.world)]   # needed_by[r] = nodes rank r must receive
-        for i, ts in train_sets.items():
-            # the result of i is needed on owner(i) and on the owners of nodes adopting it
-            dest_ranks = {int(self.owner[i])} | {int(self.owner[w]) for w, a in adopt.items() if a == i}
-            for r in dest_ranks:
-                for j in ts:
-                    if self.owner[j] != r:
-                        needed_by[r].add(j)
-        # single-group fast path: every destination shares one contributor set -> all-reduce
-        keys = {tuple(ts) for ts in train_sets.values()}
-        if self.world > 1 and len(keys) == 1:
-            contributors = list(next(iter(keys)))
-            dests = sorted(set(train_sets) | set(adopt))
-            tot = float(sum(self.weights[j] for j in contributors))
-            loc_src = [j for j in contributors if j in local_set]
-            loc_dst = [d for d in dests if d in local_set]
-            return ("allreduce", loc_src, [self.weights[j] / tot for j in loc_src], loc_dst)
-        send_lists = [sorted(j for j in needed_by[r] if self.owner[j] == me) if r != me else []
-                      for r in range(self.world)]
-        recv_lists = [sorted(j for j in needed_by[me] if self.owner[j] == r) if r != me else []
-                      for r in range(self.world)]
-        row_of = {j: j - lo for j in self.local}
-        pos = self.n_local
-        for r in range(self.world):
-            for j in recv_lists[r]:
-                row_of[j] = pos
-                pos += 1
-        # plan restricted to destinations on this rank
-        dest_rows = {j: j - lo for j in self.local}
-        ts_local, adopt_local = {}, {}
-        for i, ts in train_sets.items():
-            if i in local_set:
-                ts_local[i] = ts
-        groups: Dict[tuple, List[int]] = {}
-        for i, ts in train_sets.items():
-            dsts = ([i] if i in local_set else []) + [w for w, a in adopt.items() if a == i and w in local_set]
-            if not dsts:
-                continue
-            key = tuple(ts)
-            groups.setdefault(key, []).extend(dest_rows[d] for d in dsts)
-        plan = build_plan([([row_of[j] for j in key], [self.weights[j] for j in key], dsts)
-                           for key, dsts in groups.items()])
-        return ("rows", send_lists, recv_lists, plan, pos - self.n_local)
+        """Exchange plan of this rank (see parallel/planner.py) in the tuple form ``aggregate`` caches."""
+        ep = plan_exchange(train_sets, adopt, self.owner, self.weights, self.rank, self.world, self.local)
+        if ep.mode == "allreduce":
+            return ("allreduce", ep.local_sources, ep.local_weights, ep.local_dests)
+        return ("rows", ep.send_lists, ep.recv_lists, build_plan(ep.groups), ep.n_recv)
 
-    # ------------------------------------------------------------------ exchange primitives
-    def _round_keys(self, a: int, b: int) -> torch.Tensor:
-        key = (min(a, b), max(a, b))
-        t = self._rk_cache.get(key)
-        if t is None:
-            from ..utils.aes import expand_key
-            t = torch.tensor(list(expand_key(link_key(self.scenario, a, b))), dtype=torch.uint8, device=self.device)
-            self._rk_cache[key] = t
-        return t
-
-    def _crypt(self, buf: torch.Tensor, peer: int, decrypt: bool) -> torch.Tensor:
-        """AES-128-ECB over a [rows, P] fp32 buffer with the key of link (rank, peer)."""
-        if buf.numel() == 0:
-            return buf
-        raw = buf.view(torch.uint8).reshape(-1)
-        if buf.is_cuda:
-            from ..ops import hip
-            out = torch.empty_like(raw)
-            hip.aes128_ecb(raw, out, self._round_keys(self.rank, peer), decrypt)
-            return out.view(torch.float32).reshape(buf.shape)
-        from ..utils.aes import ecb_host
-        data = ecb_host(link_key(self.scenario, self.rank, peer), raw.numpy().tobytes(), decrypt)
-        return torch.frombuffer(bytearray(data), dtype=torch.float32).reshape(buf.shape)
-
+    # ------------------------------------------------------------------ exchange
     def _exchange_rows(self, send_lists, recv_lists, n_recv: int) -> int:
         """Move the needed parameter rows between ranks into ``self.staging``."""
         eng = self.engine
         P = eng.layout.row_stride
         if self.staging is None or self.staging.shape[0] < max(n_recv, 1):
             self.staging = torch.zeros(max(n_recv, 1), P, device=self.device)
-        if self.world == 1:
-            return 0
         lo = self.local.start
-        send_bufs = []
-        for r in range(self.world):
-            if send_lists[r]:
-                idx = torch.tensor([j - lo for j in send_lists[r]], device=self.device)
-                buf = eng.params.index_select(0, idx)
-                if self.encrypt:
-                    buf = self._crypt(buf, r, decrypt=False)
-                send_bufs.append(buf)
-            else:
-                send_bufs.append(torch.zeros(0, P, device=self.device))
-        recv_sizes = [len(l) for l in recv_lists]
-        backend = dist.get_backend(self.pg)
-        if backend == "nccl":
-            send_cat = torch.cat(send_bufs, dim=0) if sum(len(l) for l in send_lists) else torch.zeros(0, P, device=self.device)
-            recv_cat = self.staging[:n_recv] if not self.encrypt else torch.empty(n_recv, P, device=self.device)
-            dist.all_to_all_single(recv_cat, send_cat, output_split_sizes=recv_sizes,
-                                   input_split_sizes=[len(l) for l in send_lists], group=self.pg)
-        else:
-            recv_cat = torch.empty(n_recv, P, device=self.device)
-            ops, off = [], 0
-            for r in range(self.world):
-                if recv_sizes[r]:
-                    ops.append(dist.P2POp(dist.irecv, recv_cat[off:off + recv_sizes[r]], r, group=self.pg))
-                    off += recv_sizes[r]
-                if send_lists[r]:
-                    ops.append(dist.P2POp(dist.isend, send_bufs[r].contiguous(), r, group=self.pg))
-            if ops:
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()
-        if self.encrypt:
-            off = 0
-            for r in range(self.world):
-                if recv_sizes[r]:
-                    self.staging[off:off + recv_sizes[r]] = self._crypt(recv_cat[off:off + recv_sizes[r]].contiguous(), r, True)
-                    off += recv_sizes[r]
-        elif recv_cat.data_ptr() != self.staging.data_ptr():
-            self.staging[:n_recv] = recv_cat
-        return n_recv
+        return self.comm.exchange_rows(eng.params, [[j - lo for j in l] for l in send_lists],
+                                       [len(l) for l in recv_lists], self.staging)
 
     # ------------------------------------------------------------------ the round
     def _apply_faults(self) -> None:
@@ -310,16 +192,7 @@ class BatchedFederation:
                                        torch.tensor([0, 1], dtype=torch.int32, device=self.device),
                                        torch.tensor([0], dtype=torch.int32, device=self.device), 1)
                 run_plan(eng.params, None, partial, plan)
-            if self.encrypt:
-                # all-reduce has no per-link ciphertext form: fall back to an encrypted all-gather
-                rows = [torch.empty_like(partial) for _ in range(self.world)]
-                enc = [self._crypt(partial, r, False) if r != self.rank else partial for r in range(self.world)]
-                outs = [torch.empty_like(partial) for _ in range(self.world)]
-                dist.all_to_all(outs, enc, group=self.pg) if dist.get_backend(self.pg) == "nccl" else \
-                    self._gloo_all_to_all(outs, enc)
-                partial = sum(self._crypt(o, r, True) if r != self.rank else o for r, o in enumerate(outs))
-            else:
-                dist.all_reduce(partial, group=self.pg)
+            partial = self.comm.allreduce_partial(partial)
             if loc_dst:
                 idx = torch.tensor([d - lo for d in loc_dst], device=self.device)
                 out[idx] = partial.expand(len(loc_dst), -1)
@@ -330,17 +203,6 @@ class BatchedFederation:
         run_plan(eng.params, self.staging, out, plan)
         eng.swap_slabs()
         return got
-
-    def _gloo_all_to_all(self, outs, ins) -> None:
-        ops = []
-        for r in range(self.world):
-            if r == self.rank:
-                outs[r].copy_(ins[r])
-                continue
-            ops.append(dist.P2POp(dist.irecv, outs[r], r, group=self.pg))
-            ops.append(dist.P2POp(dist.isend, ins[r].contiguous(), r, group=self.pg))
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
 
     def _transfer_leadership(self) -> None:
         """SDFL: the aggregator hands its role to a random live neighbour (node.py:676-686)."""

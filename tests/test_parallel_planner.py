@@ -1,0 +1,87 @@
+"""Structural checks of the topology -> collective planner for 2..8 ranks, on the CPU: what rank a
+sends to rank b is exactly what b expects from a (same rows, same order), every destination gets all
+of its contributors, and the fully connected / star cases collapse to one all-reduce."""
+import numpy as np
+import pytest
+
+from p2pfl_amd.parallel.planner import (estimate_exchange_seconds, owner_of, partition_nodes, plan_exchange)
+from p2pfl_amd.utils.topologymanager import TopologyManager
+
+
+def _structure(adj, roles=None):
+    n = adj.shape[0]
+    ts = {i: sorted([int(j) for j in np.nonzero(adj[i])[0] if j != i] + [i]) for i in range(n)}
+    return ts, {}
+
+
+def _plans(adj, world):
+    n = adj.shape[0]
+    owner = owner_of(n, world)
+    ts, adopt = _structure(adj)
+    w = [100.0 + i for i in range(n)]
+    blocks = partition_nodes(n, world)
+    return ts, [plan_exchange(ts, adopt, owner, w, r, world, blocks[r]) for r in range(world)], blocks, w
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("kind", ["ring", "random"])
+def test_rows_mode_send_recv_symmetry(world, kind):
+    n = 50
+    tm = TopologyManager(n_nodes=n, b_symmetric=True, undirected_neighbor_num=3)
+    tm.generate_ring_topology(increase_convergence=False) if kind == "ring" else tm.generate_topology()
+    adj = np.asarray(tm.get_topology())
+    ts, plans, blocks, w = _plans(adj, world)
+    assert all(p.mode == "rows" for p in plans)
+    for a in range(world):
+        assert plans[a].send_lists[a] == [] and plans[a].recv_lists[a] == []
+        for b in range(world):
+            assert plans[a].send_lists[b] == plans[b].recv_lists[a]          # same rows, same order
+            assert all(j in blocks[a] for j in plans[a].send_lists[b])        # only rows we own
+    for r, p in enumerate(plans):
+        assert p.n_recv == sum(len(l) for l in p.recv_lists)
+        rows = sorted(p.row_of.values())
+        assert rows == list(range(len(blocks[r]) + p.n_recv))                 # dense source pool
+        # every local aggregating node finds all of its contributors in the pool, with the right weights
+        covered = set()
+        inv = {v: k for k, v in p.row_of.items()}
+        for srcs, ws, dsts in p.groups:
+            contrib = sorted(inv[s] for s in srcs)
+            assert ws == [w[j] for j in [inv[s] for s in srcs]]
+            for d in dsts:
+                node = blocks[r].start + d
+                assert ts[node] == contrib
+                covered.add(node)
+        assert covered == set(blocks[r])
+    # a ring only talks to the neighbouring blocks: at most 2 rows per peer and direction... per boundary
+    if kind == "ring":
+        assert max(p.rows_sent() for p in plans) <= 4
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_fully_connected_and_star_collapse_to_allreduce(world):
+    n = 40
+    full = np.ones((n, n)) - np.eye(n)
+    ts, plans, blocks, w = _plans(full, world)
+    assert all(p.mode == "allreduce" for p in plans)
+    tot = sum(w)
+    assert abs(sum(sum(p.local_weights) for p in plans) - 1.0) < 1e-9
+    for r, p in enumerate(plans):
+        assert p.local_sources == list(blocks[r]) and p.local_dests == list(blocks[r])
+        assert np.allclose(p.local_weights, [w[j] / tot for j in blocks[r]])
+    # CFL star: only the server aggregates, every other node adopts its result
+    owner = owner_of(n, world)
+    ts = {0: list(range(n))}
+    adopt = {i: 0 for i in range(1, n)}
+    plans = [plan_exchange(ts, adopt, owner, w, r, world, blocks[r]) for r in range(world)]
+    assert all(p.mode == "allreduce" for p in plans)
+    assert sorted(d for p in plans for d in p.local_dests) == list(range(n))
+
+
+def test_exchange_time_model_is_per_link():
+    n, world = 800, 8
+    full = np.ones((n, n)) - np.eye(n)
+    _, plans, _, _ = _plans(full, world)
+    row_bytes = 6_497_162 * 4
+    t = estimate_exchange_seconds(plans[0], row_bytes, world)
+    assert 0.2e-4 < t < 1e-4            # ~26 MB all-reduce over 7 links: tens of microseconds, not milliseconds
+    assert estimate_exchange_seconds(plans[0], row_bytes, 1) == 0.0

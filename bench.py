@@ -37,6 +37,17 @@ from p2pfl_amd.utils.topologymanager import TopologyManager  # noqa: E402
 EAGER_BASELINE_SAMPLES_PER_SEC = 30324.8   # profiles/r1_eager_baseline.json (1x MI355X, fp32, 100 nodes)
 
 
+# the other BASELINE.json configurations (the default flags are #4 without encryption/churn = the headline)
+PRESETS = {
+    "cnn10-fully": dict(model="mnist-cnn", nodes_per_gpu=10, split_nodes=10, topology="fully"),
+    "femnist50-ring": dict(model="femnist-cnn", nodes_per_gpu=50, split_nodes=50, topology="ring"),
+    "cnn100-encrypted-churn": dict(model="mnist-cnn", nodes_per_gpu=100, split_nodes=100, topology="random",
+                                   encrypt=True, churn=0.1),
+    "femnist1000-star": dict(model="femnist-cnn", nodes_per_gpu=1000, split_nodes=1000, topology="star",
+                             federation="CFL"),
+}
+
+
 def build_topology(kind: str, n: int, seed: int):
     tm = TopologyManager(n_nodes=n, b_symmetric=True, undirected_neighbor_num=max(n - 1, 2) if kind == "fully" else 3,
                          seed=seed)
@@ -70,7 +81,14 @@ def main() -> None:
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--split-nodes", type=int, default=100,
                     help="data shards are sized as in an N-node split of MNIST (reference mnist.py:100-118)")
+    ap.add_argument("--churn", type=float, default=0.0,
+                    help="fraction of nodes killed one round after warm-up and revived two rounds later")
+    ap.add_argument("--config", default=None, choices=sorted(PRESETS),
+                    help="one of the other BASELINE.json configurations (overrides the flags it names)")
     args = ap.parse_args()
+    if args.config:
+        for k, v in PRESETS[args.config].items():
+            setattr(args, k, v)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -108,6 +126,12 @@ def main() -> None:
         if device.type == "cuda":
             torch.cuda.synchronize()
 
+    if args.churn > 0:
+        import random
+        victims = random.Random(args.seed).sample(range(1, n_nodes), max(1, int(args.churn * n_nodes)))
+        for v in victims:
+            fed.schedule_fault(args.warmup + 1, "kill", v)
+            fed.schedule_fault(args.warmup + 3, "revive", v)
     for _ in range(args.warmup):
         fed.run_round(sync_timing=False)
     sync()
@@ -131,7 +155,8 @@ def main() -> None:
         sps = samples / elapsed
         steps_per_epoch = -(-n_tr // args.batch_size)
         out = {
-            "metric": "aggregate client samples/sec (federated rounds, MNIST CNN, 100 nodes per GPU)",
+            "metric": "aggregate client samples/sec (federated rounds, MNIST CNN, 100 nodes per GPU)"
+            if args.config is None else f"aggregate client samples/sec (federated rounds, {args.config})",
             "value": sps,
             "unit": "samples/s",
             "n_gpus": world,
@@ -140,7 +165,8 @@ def main() -> None:
             "ms_per_step": 1000.0 * elapsed / args.steps,
             "higher_is_better": True,
             "scaling": args.scaling,
-            "vs_baseline": (sps / (EAGER_BASELINE_SAMPLES_PER_SEC * world)) if EAGER_BASELINE_SAMPLES_PER_SEC else None,
+            "vs_baseline": (sps / (EAGER_BASELINE_SAMPLES_PER_SEC * world))
+            if EAGER_BASELINE_SAMPLES_PER_SEC and args.config is None else None,
             "dtype": "bf16" if args.impl == "hip" else "fp32",
             "data": "synthetic",
             "rounds_per_sec": args.steps / elapsed,
@@ -150,6 +176,7 @@ def main() -> None:
                 "global_batch": args.batch_size * n_nodes, "batch_per_node": args.batch_size,
                 "train_samples_per_node": n_tr, "optimizer_steps_per_round": steps_per_epoch * args.epochs,
                 "seq_len": None, "parallelism": f"fdp{world}x{fed.n_local}", "encrypt": args.encrypt,
+                "churn": args.churn, "preset": args.config,
                 "last_test_accuracy_mean": None if last is None or last.test_accuracy is None
                 else float(last.test_accuracy.mean()),
             },

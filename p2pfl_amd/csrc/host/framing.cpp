@@ -46,7 +46,9 @@ API size_t p2pfl_params_build(const uint8_t* data, size_t n, size_t block, uint8
         const size_t take = (n - off < cap) ? n - off : cap;
         std::memcpy(out + w, HDR, HDR_LEN);
         std::memcpy(out + w + HDR_LEN, data + off, take);
-        if (take < cap) std::memset(out + w + HDR_LEN + take, 0, cap - take);   // unreachable: take == cap here
+        // a tail of block-12 .. block-7 bytes cannot share a frame with the closing tag: it is zero padded
+        // (< 7 bytes; the payload is a pickle, whose reader stops at its STOP opcode)
+        if (take < cap) std::memset(out + w + HDR_LEN + take, 0, cap - take);
         off += take;
         w += block;
     }

@@ -1,0 +1,42 @@
+"""ASan + UBSan and TSan builds of the host C++ runtime (the reference has no race or memory
+checking at all). Host code only: the GPU kernels are covered by the numerics tests.
+
+The sanitizer runtimes are linked statically and the child inherits the environment unchanged. A sanitizer
+that refuses to start in this environment (it wants to be the first library loaded) makes the test skip."""
+import shutil
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+SRCS = sorted((ROOT / "p2pfl_amd" / "csrc" / "host").glob("*.cpp"))
+DRIVER = ROOT / "tests" / "native" / "host_driver.cpp"
+_CANNOT_START = ("runtime does not come first", "incompatible with", "unexpected memory mapping",
+                 "failed to intercept", "Shadow memory range interleaves")
+
+
+def _build_and_run(tmp_path, flags):
+    cxx = shutil.which("g++")
+    if cxx is None:
+        pytest.skip("no g++")
+    exe = tmp_path / "host_driver"
+    cmd = [cxx, "-O1", "-g", "-std=c++17", "-maes", "-msse4.1", "-pthread", "-fno-omit-frame-pointer", *flags,
+           "-o", str(exe), str(DRIVER)] + [str(s) for s in SRCS]
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    if b.returncode != 0 and ("cannot find" in b.stderr or "unrecognized" in b.stderr):
+        pytest.skip("sanitizer runtime not installed: " + b.stderr[-200:])
+    assert b.returncode == 0, b.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    if r.returncode != 0 and any(m in r.stderr for m in _CANNOT_START):
+        pytest.skip("sanitizer cannot start in this environment: " + r.stderr.strip().splitlines()[0][:200])
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_host_runtime_asan_ubsan(tmp_path):
+    _build_and_run(tmp_path, ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-static-libasan",
+                              "-static-libubsan"])
+
+
+def test_host_runtime_tsan(tmp_path):
+    _build_and_run(tmp_path, ["-fsanitize=thread", "-static-libtsan"])

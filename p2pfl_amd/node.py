@@ -90,6 +90,7 @@ class Node(BaseNode):
         # gates
         self._init_model_ready = threading.Event()      # initial weights installed
         self._aggregation_done = threading.Event()      # this round's aggregate was adopted
+        self._round_lock = threading.RLock()            # round advance vs. intake of a decoded payload
         self._model_queue: "queue.Queue[bytes]" = queue.Queue()
         self._model_worker = threading.Thread(target=self._model_worker_loop, name="models-" + self.get_name(),
                                               daemon=True)
@@ -178,6 +179,7 @@ class Node(BaseNode):
             if self.round is not None:
                 return
             self.round = 0
+            self._aggregation_done.clear()
             self.totalrounds = rounds
         self.learner.init()
         begin = time.time()
@@ -219,14 +221,19 @@ class Node(BaseNode):
             if m is None:
                 return
             try:
-                self.add_model(m)
+                self.add_model(*m) if isinstance(m, tuple) else self.add_model(m)
             except Exception as e:
                 logging.exception(e)
 
-    def add_model(self, m):
-        """A complete payload arrived: either the initial model, or a (partial) aggregate."""
+    def add_model(self, m, payload_round=None):
+        """A complete payload arrived: either the initial model, or a (partial) aggregate.
+        ``payload_round``: round the link attributes the payload to (NodeConnection.payload_round);
+        a late duplicate of the previous round must not count as a contribution to this one."""
         if self.round is None:
             logging.error("[NODE] Tried to add a model while learning is not running")
+            return
+        if self._model_initialized and payload_round is not None and payload_round != self.round:
+            logging.debug("[NODE] dropped a payload of round %s in round %s", payload_round, self.round)
             return
         try:
             if not self._model_initialized:
@@ -243,17 +250,22 @@ class Node(BaseNode):
             if not self.learner.check_parameters(decoded):
                 raise ModelNotMatchingError("Not matching models")
             waits = Role.waits(self.role)
-            if waits and (not self._local_done or self._aggregation_done.is_set()):
-                # duplicate of last round's diffusion, or a model for a round we have not contributed
-                # to yet: the reference's non-waiting aggregator ignores it too (aggregator.py:177-178)
-                return
-            early_aggregate = waits and not self.aggregator.get_waiting_aggregated_model() and (
-                contributors is None or (self.get_name() in contributors and len(contributors) > 1))
-            if early_aggregate:
-                # the aggregate overtook our own "waiting" transition: adopt it now
-                self.update(Events.AGGREGATION_FINISHED_EVENT, decoded)
-                return
-            models_added = self.aggregator.add_model(decoded, contributors, weight, check=False)
+            with self._round_lock:     # decoding took milliseconds: the round may have advanced meanwhile
+                if payload_round is not None and payload_round != self.round:
+                    return
+                if self._aggregation_done.is_set():
+                    return      # this round's aggregate is already in place: a duplicate must not be re-announced
+                if waits and not self._local_done:
+                    # a model for a round we have not contributed to yet: the reference's non-waiting
+                    # aggregator ignores it too (aggregator.py:177-178)
+                    return
+                early_aggregate = waits and not self.aggregator.get_waiting_aggregated_model() and (
+                    contributors is None or (self.get_name() in contributors and len(contributors) > 1))
+                if early_aggregate:
+                    # the aggregate overtook our own "waiting" transition: adopt it now
+                    self.update(Events.AGGREGATION_FINISHED_EVENT, decoded)
+                    return
+                models_added = self.aggregator.add_model(decoded, contributors, weight, check=False)
             if models_added is not None:
                 self.broadcast(CommunicationProtocol.build_models_aggregated_msg(models_added))
                 self.aggregator.check_and_run_aggregation()
@@ -274,7 +286,6 @@ class Node(BaseNode):
         if self.get_name() not in self._train_set:
             self._train_set.append(self.get_name())
         self._validate_train_set()
-        self._aggregation_done.clear()
         self._ready_sent = False
         self._local_done = Role.waits(self.role) and not Role.trains(self.role)   # proxy / idle: nothing to do
         role = self.role
@@ -286,9 +297,11 @@ class Node(BaseNode):
             if self.round is not None and role != Role.SERVER:      # the CFL server never trains
                 self._train()
             if self.round is not None:
+                # announce first: adding the last missing model aggregates and sends MODELS_READY, and the
+                # link-order rule (NodeConnection.payload_round) needs MODELS_AGGREGATED before it
+                self.broadcast(CommunicationProtocol.build_models_aggregated_msg([self.get_name()]))
                 self.aggregator.add_model(self.learner.get_parameters(), [self.get_name()],
                                           self.learner.get_num_samples()[0])
-                self.broadcast(CommunicationProtocol.build_models_aggregated_msg([self.get_name()]))
                 if role == Role.SERVER:
                     self._gossip_model_difusion()
                 else:
@@ -304,9 +317,9 @@ class Node(BaseNode):
                 self._train()
             if self.round is not None:
                 self._local_done = True
+                self.broadcast(CommunicationProtocol.build_models_aggregated_msg([self.get_name()]))
                 self.aggregator.add_model(self.learner.get_parameters(), [self.get_name()],
                                           self.learner.get_num_samples()[0])
-                self.broadcast(CommunicationProtocol.build_models_aggregated_msg([self.get_name()]))
                 self._gossip_model_aggregation()
                 if not self._aggregation_done.is_set():
                     self.aggregator.set_waiting_aggregated_model()
@@ -367,11 +380,14 @@ class Node(BaseNode):
         for nc in self.get_neighbors():
             if nc not in self._initial_neighbors:
                 self.rm_neighbor(nc)
-        self.aggregator.clear()
+        with self._round_lock:
+            self.aggregator.clear()
+            if self.round is not None:
+                self.round += 1
+                self._aggregation_done.clear()
         self.learner.finalize_round()
         if self.round is None:
             return True
-        self.round += 1
         if self.learner.logger is not None:
             self.learner.logger.log_metrics({"Round": self.round}, step=self.learner.logger.global_step)
         self._train_set = []     # per-peer MODELS_AGGREGATED lists are reset when the peer's MODELS_READY arrives

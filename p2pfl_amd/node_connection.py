@@ -49,6 +49,7 @@ class NodeConnection(threading.Thread, Observable):
         self.__model_ready = -1
         self.__model_initialized = False
         self.__models_aggregated = []
+        self.__fresh = False      # peer announced contributions (MODELS_AGGREGATED) since its last MODELS_READY
         self.__lib = hostlib.load()
         self.__param_buffer = self.__lib.p2pfl_reasm_new(1 << 20)
         self.__force = False
@@ -216,6 +217,7 @@ class NodeConnection(threading.Thread, Observable):
         with self.__state_lock:
             self.__model_ready = round
             self.__models_aggregated = []
+            self.__fresh = False
 
     def get_model_ready_status(self):
         with self.__state_lock:
@@ -232,6 +234,15 @@ class NodeConnection(threading.Thread, Observable):
     def add_models_aggregated(self, models):
         with self.__state_lock:
             self.__models_aggregated = list(set(models + self.__models_aggregated))
+            self.__fresh = True
+
+    def payload_round(self):
+        """Round a payload arriving NOW on this link belongs to. PARAMS frames carry no round number,
+        but the link is ordered: a peer announces MODELS_READY r when it holds round r's model and
+        MODELS_AGGREGATED before the first payload of the next round, so everything after READY r and
+        before that announcement still belongs to round r (late duplicates, diffusion of the aggregate)."""
+        with self.__state_lock:
+            return self.__model_ready + (1 if self.__fresh else 0)
 
     def clear_models_aggregated(self):
         with self.__state_lock:
@@ -275,7 +286,7 @@ class NodeConnection(threading.Thread, Observable):
         self.notify(Events.STOP_LEARNING_EVENT, None)
 
     def notify_params(self, params):
-        self.notify(Events.PARAMS_RECEIVED_EVENT, params)
+        self.notify(Events.PARAMS_RECEIVED_EVENT, (params, self.payload_round()))
 
     def notify_metrics(self, node, round, loss, metric):
         self.notify(Events.METRICS_RECEIVED_EVENT, (node, round, loss, metric))

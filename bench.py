@@ -77,6 +77,7 @@ def main() -> None:
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--encrypt", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="single-stream schedule (A/B against the two-stream pipeline)")
     ap.add_argument("--cpu", action="store_true", help="debug: run on the CPU with gloo")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--split-nodes", type=int, default=100,
@@ -112,7 +113,7 @@ def main() -> None:
     fed = BatchedFederation(spec, topo, federation=args.federation, device=device, engine=args.impl,
                             batch_size=args.batch_size, epochs=args.epochs, seed=args.seed, rank=rank,
                             world_size=world, process_group=pg, encrypt=args.encrypt,
-                            use_graph=not args.no_graph)
+                            use_graph=not args.no_graph, overlap=not args.no_overlap)
     # shard sizes of the named 100-node split (reference mnist.py:100-118)
     n_tr, n_va, n_te = reference_shard_sizes(args.split_nodes)
     tx, ty, vx, vy, ex, ey = synthetic_shards(fed.n_local, n_tr, n_va, n_te, spec.num_classes, seed=args.seed,

@@ -17,6 +17,7 @@ Both share the slab layout, so aggregation / exchange code is engine-agnostic.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -231,7 +232,7 @@ class EagerEngine(ShardEngine):
 class HipEngine(ShardEngine):
     """Client-batched gfx950 kernels + hipGraph replay (see module docstring)."""
 
-    def __init__(self, *a, use_graph: bool = True, fuse_optimizer: bool = True, **kw):
+    def __init__(self, *a, use_graph: bool = True, fuse_optimizer: bool = True, overlap: bool = True, **kw):
         super().__init__(*a, **kw)
         if self.device.type != "cuda":
             raise RuntimeError("HipEngine needs a GPU device")
@@ -286,6 +287,14 @@ class HipEngine(ShardEngine):
         self._perm_buf = None
         self._bc_buf = None
         self._eval_graph = None
+        # Two-stream software pipeline (see _train_body_pipelined): only pays when the first dense layer
+        # behind the convolutions is a big fused wgrad+Adam layer (HBM-bound for milliseconds) under
+        # which the MFMA/LDS-bound convolution kernels can hide.
+        self.nc = sum(1 for l in self.spec.layers if l.kind != "linear")
+        self.overlap = bool(overlap) and self.nc > 0 and self.nc in self._fused
+        if self.overlap:
+            self._side = torch.cuda.Stream(device=dev, priority=int(os.environ.get('P2PFL_SIDE_PRIO', '-1')))
+            self._act_pp = [self.act[self.nc - 1], torch.zeros_like(self.act[self.nc - 1])]
 
     # ------------------------------------------------------------------ helpers
     def _w(self, slab, l):
@@ -429,6 +438,106 @@ class HipEngine(ShardEngine):
             if self.val_x is not None:
                 self._eval_pass(self.val_x, self.val_y, "Validation")
 
+    # ------------------------------------------------------------------ two-stream pipeline
+    def _conv_forward(self, data, sidx, out_last) -> None:
+        """Convolution stages of one batch; the last stage writes ``out_last``."""
+        hip, x = self.hip, None
+        for i in range(self.nc):
+            l = self.spec.layers[i]
+            W, b = self._w(self.params, l)
+            out = out_last if i == self.nc - 1 else self.act[i]
+            if l.kind == "conv1pool":
+                hip.conv1_fwd(data, sidx, W, b, out, self.code[i], l.ksize)
+            else:
+                hip.conv2_prep(W, self.wprep[i], l.ksize)
+                hip.conv2_fwd(x, W, b, out, self.code[i], l.ksize, wprep=self.wprep[i])
+            x = out
+
+    def _conv_backward(self, data, sidx) -> None:
+        hip = self.hip
+        for i in range(self.nc - 1, -1, -1):
+            l = self.spec.layers[i]
+            W, _ = self._w(self.params, l)
+            gW, gb = self._w(self.grads, l)
+            if l.kind == "conv2pool":
+                hip.conv2_wgrad(self.dact[i], self.code[i], self.act[i - 1], gW, gb, l.ksize)
+                hip.conv2_dgrad(self.dact[i], self.code[i], W, self.dact[i - 1], l.ksize, wprep=self.wprep[i])
+            else:
+                hip.conv1_wgrad(self.dact[i], self.code[i], data, sidx, gW, gb, l.ksize)
+
+    def _dense_step(self, conv_out, labels, sidx, n_valid, step_index: int, side) -> None:
+        """Dense layers of one training step on the current stream: forward, loss, backward. ``side`` is
+        released (it may start the convolution backward pass) as soon as the data gradient of the first
+        dense layer exists, i.e. BEFORE that layer's long fused wgrad+Adam kernel is enqueued."""
+        hip, layers, nc, o = self.hip, self.spec.layers, self.nc, self.spec.optim
+        main = torch.cuda.current_stream()
+        x = conv_out.flatten(2)
+        for i in range(nc, len(layers)):
+            W, b = self._w(self.params, layers[i])
+            hip.linear_fwd(x, W, b, self.act[i], layers[i].relu)
+            x = self.act[i]
+        st = self.stats["Train"]
+        hip.softmax_ce(x, labels, sidx, self.dact[-1], st.loss_sum, st.correct, st.count, st.confusion, n_valid)
+        for i in range(len(layers) - 1, nc - 1, -1):
+            l = layers[i]
+            W, _ = self._w(self.params, l)
+            xin = conv_out.flatten(2) if i == nc else self.act[i - 1]
+            prev = layers[i - 1]
+            mask = self.act[i - 1] if (prev.kind == "linear" and prev.relu) else None
+            hip.linear_dgrad(self.dact[i], W, mask, self.dact[i - 1].flatten(2))
+            if i == nc:
+                side.wait_stream(main)
+            if i in self._fused:
+                Wb, Mb, Vb = self._w(self.params, l), self._w(self.m, l), self._w(self.v, l)
+                hip.linear_wgrad_adam(self.dact[i], xin, Wb[0], Mb[0], Vb[0], Wb[1], Mb[1], Vb[1], lr=o.lr,
+                                      beta1=o.beta1, beta2=o.beta2, eps=o.eps, weight_decay=o.weight_decay,
+                                      t=step_index, bc=self._bc_buf[step_index - 1])
+            else:
+                gW, gb = self._w(self.grads, l)
+                hip.linear_wgrad(self.dact[i], xin, gW, gb)
+
+    def _train_body_pipelined(self, epochs: int, steps: int, n: int) -> None:
+        """Same work as :meth:`_train_body`, scheduled on two HIP streams (graph branches when captured):
+
+            main : [dense fwd + loss + dense bwd ....... fused wgrad+Adam of the big layer (HBM-bound)] ...
+            side :              [conv bwd | Adam of the small layers | conv fwd of the NEXT batch]
+
+        The convolution kernels are MFMA/LDS-bound and short, the fused update streams weights and both
+        Adam moments of every client through HBM for milliseconds with idle matrix cores, so the two
+        overlap. The output of the last convolution stage is double-buffered because the fused update of
+        step t still reads it while the side stream already produces the one of step t+1.
+        """
+        main, side = torch.cuda.current_stream(), self._side
+        nv_last = self._nv(n - (steps - 1) * self.B)
+        for ph in ("Train", "Validation"):
+            self.stats[ph].zero_()
+        t = 0
+        for e in range(epochs):
+            if e == epochs - 1 and epochs > 1:
+                for ph in ("Train", "Validation"):
+                    self.stats[ph].zero_()
+            self._conv_forward(self.train_x, self._perm_buf[e, :, :self.B], self._act_pp[t & 1])
+            for s in range(steps):
+                sidx = self._perm_buf[e, :, s * self.B:(s + 1) * self.B]
+                nv = nv_last if s == steps - 1 else self._nv(self.B)
+                t += 1
+                self._dense_step(self._act_pp[(t - 1) & 1], self.train_y, sidx, nv, t, side)
+                with torch.cuda.stream(side):
+                    self._conv_backward(self.train_x, sidx)
+                    self._optim_step(t)
+                    if s + 1 < steps:
+                        self._conv_forward(self.train_x, self._perm_buf[e, :, (s + 1) * self.B:(s + 2) * self.B],
+                                           self._act_pp[t & 1])
+                main.wait_stream(side)
+            if self.val_x is not None:
+                self._eval_pass(self.val_x, self.val_y, "Validation")
+
+    def _train(self, epochs: int, steps: int, n: int) -> None:
+        if self.overlap:
+            self._train_body_pipelined(epochs, steps, n)
+        else:
+            self._train_body(epochs, steps, n)
+
     def fit(self, epochs, active=None):
         if not self.persist_optimizer:
             self.reset_optimizer()
@@ -462,7 +571,7 @@ class HipEngine(ShardEngine):
                 s.wait_stream(torch.cuda.current_stream())
                 snap = (self.params.clone(), self.m.clone(), None if self.v is None else self.v.clone())
                 with torch.cuda.stream(s):
-                    self._train_body(1, min(steps, 2), n)
+                    self._train(1, min(steps, 2), n)
                 torch.cuda.current_stream().wait_stream(s)
                 torch.cuda.synchronize()
                 self.params.copy_(snap[0]); self.m.copy_(snap[1])
@@ -470,14 +579,14 @@ class HipEngine(ShardEngine):
                     self.v.copy_(snap[2])
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    self._train_body(epochs, steps, n)
+                    self._train(epochs, steps, n)
                 self._graphs[key] = (g,)
                 self.params.copy_(snap[0]); self.m.copy_(snap[1])
                 if self.v is not None:
                     self.v.copy_(snap[2])
             self._graphs[key][0].replay()
         else:
-            self._train_body(epochs, steps, n)
+            self._train(epochs, steps, n)
         self.opt_steps += total
         if saved is not None:
             self.params[saved[0]] = saved[1]
@@ -517,4 +626,5 @@ def make_engine(spec: ModelSpec, n_clients: int, device, impl: str = "auto", **k
     if impl == "hip":
         return HipEngine(spec, n_clients, device, **kw)
     kw.pop("use_graph", None)
+    kw.pop("overlap", None)
     return EagerEngine(spec, n_clients, device, **kw)

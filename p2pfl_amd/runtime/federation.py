@@ -59,7 +59,8 @@ class BatchedFederation:
     def __init__(self, spec: ModelSpec, topology, *, federation: str = "DFL", roles: Optional[Sequence[str]] = None,
                  device="cpu", engine: str = "auto", batch_size: int = 32, epochs: int = 1, seed: int = 0,
                  rank: int = 0, world_size: int = 1, process_group=None, encrypt: bool = False,
-                 scenario: str = "scenario", persist_optimizer: bool = False, use_graph: bool = True):
+                 scenario: str = "scenario", persist_optimizer: bool = False, use_graph: bool = True,
+                 overlap: bool = True):
         self.spec = spec
         self.adj = np.asarray(topology, dtype=np.float32)
         self.N = self.adj.shape[0]
@@ -79,7 +80,7 @@ class BatchedFederation:
         self.n_local = len(self.local)
         self.engine: ShardEngine = make_engine(spec, self.n_local, self.device, impl=engine, batch_size=batch_size,
                                                seed=seed, persist_optimizer=persist_optimizer,
-                                               **({"use_graph": use_graph} if engine != "eager" else {}))
+                                               **({"use_graph": use_graph, "overlap": overlap} if engine != "eager" else {}))
         self.alive = np.ones(self.N, dtype=bool)
         self.weights = np.zeros(self.N, dtype=np.float64)       # training samples per node
         self.round = 0

@@ -88,32 +88,34 @@ class DeviceExchange:
         if self.world == 1:
             return 0
         P = params.shape[1]
-        send_bufs = []
-        for r in range(self.world):
-            if len(send_rows[r]):
-                idx = torch.as_tensor(list(send_rows[r]), device=self.device)
-                buf = params.index_select(0, idx)
-                if self.encrypt:
-                    buf = self.crypt(buf, r, decrypt=False)
-                send_bufs.append(buf)
-                self.bytes_sent += buf.numel() * 4
-            else:
-                send_bufs.append(torch.zeros(0, P, device=self.device))
         send_counts = [len(l) for l in send_rows]
+        flat = [int(j) for l in send_rows for j in l]
+        # ONE gather builds the peer-major send buffer (rows of a 26 MB model: no per-peer temporaries)
+        if flat:
+            send_cat = params.index_select(0, torch.as_tensor(flat, device=self.device))
+        else:
+            send_cat = params.new_zeros(0, P)
+        self.bytes_sent += send_cat.numel() * 4
+        if self.encrypt:
+            off = 0
+            for r, c in enumerate(send_counts):
+                if c:
+                    send_cat[off:off + c] = self.crypt(send_cat[off:off + c], r, decrypt=False)
+                    off += c
         if self._backend() == "nccl":
-            send_cat = torch.cat(send_bufs, dim=0) if sum(send_counts) else torch.zeros(0, P, device=self.device)
             recv_cat = staging[:n_recv] if not self.encrypt else torch.empty(n_recv, P, device=self.device)
             dist.all_to_all_single(recv_cat, send_cat, output_split_sizes=list(recv_counts),
                                    input_split_sizes=send_counts, group=self.pg)
         else:
             recv_cat = torch.empty(n_recv, P, device=self.device)
-            ops, off = [], 0
+            ops, off, soff = [], 0, 0
             for r in range(self.world):
                 if recv_counts[r]:
                     ops.append(dist.P2POp(dist.irecv, recv_cat[off:off + recv_counts[r]], r, group=self.pg))
                     off += recv_counts[r]
                 if send_counts[r]:
-                    ops.append(dist.P2POp(dist.isend, send_bufs[r].contiguous(), r, group=self.pg))
+                    ops.append(dist.P2POp(dist.isend, send_cat[soff:soff + send_counts[r]], r, group=self.pg))
+                    soff += send_counts[r]
             if ops:
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()

@@ -13,6 +13,7 @@ from __future__ import annotations
 import argparse
 import datetime
 import glob
+import hashlib
 import io
 import json
 import os
@@ -115,7 +116,8 @@ def fedstellar_delete_user(user):
 def fedstellar_scenario_private(scenario_name):
     if "user" not in session:
         return abort(401)
-    return render_template("private.html", scenario_name=_safe(scenario_name), notes=db.read_note_from_db(session["user"]))
+    return render_template("private.html", scenario_name=_safe(scenario_name), notes=db.read_note_from_db(session["user"]),
+                           images=db.list_images_for_user(session["user"]))
 
 
 @app.route("/write_note", methods=["POST"])
@@ -131,6 +133,56 @@ def fedstellar_delete_note(note_id):
     if session.get("user") != db.match_user_id_with_note_id(note_id):
         return abort(401)
     db.delete_note_from_db(note_id)
+    return redirect(request.referrer or url_for("fedstellar_scenario"))
+
+
+# ------------------------------------------------------------------ images (reference app.py:131-192)
+def _upload_dir():
+    d = app.config["UPLOAD_FOLDER"]
+    if not os.path.isabs(d):
+        d = os.path.join(os.environ.get("FEDSTELLAR_DB_DIR") or os.path.dirname(os.path.abspath(__file__)), d)
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def allowed_file(filename: str) -> bool:
+    return "." in filename and filename.rsplit(".", 1)[1].lower() in app.config["ALLOWED_EXTENSIONS"]
+
+
+@app.route("/upload_image", methods=["POST"])
+def fedstellar_upload_image():
+    if "user" not in session:
+        return abort(401)
+    back = request.referrer or url_for("fedstellar_scenario")
+    file = request.files.get("file")
+    if file is None or file.filename == "" or not allowed_file(file.filename):
+        return redirect(back)
+    from werkzeug.utils import secure_filename
+    filename = secure_filename(file.filename)
+    upload_time = str(datetime.datetime.now())
+    image_uid = hashlib.sha1((upload_time + filename).encode()).hexdigest()
+    file.save(os.path.join(_upload_dir(), image_uid + "-" + filename))
+    db.image_upload_record(image_uid, session["user"], filename, upload_time)
+    return redirect(back)
+
+
+@app.route("/images/<image_uid>/", methods=["GET"])
+def fedstellar_get_image(image_uid):
+    if session.get("user") is None or session.get("user") != db.match_user_id_with_image_uid(_safe(image_uid)):
+        return abort(401)
+    path = os.path.join(_upload_dir(), db.get_image_file_name(image_uid))
+    return send_file(path) if os.path.exists(path) else abort(404)
+
+
+@app.route("/delete_image/<image_uid>", methods=["GET"])
+def fedstellar_delete_image(image_uid):
+    if session.get("user") is None or session.get("user") != db.match_user_id_with_image_uid(_safe(image_uid)):
+        return abort(401)
+    name = db.get_image_file_name(image_uid)
+    db.delete_image_from_db(image_uid)
+    path = os.path.join(_upload_dir(), name)
+    if os.path.exists(path):
+        os.remove(path)
     return redirect(request.referrer or url_for("fedstellar_scenario"))
 
 
@@ -235,16 +287,67 @@ def _tail(path, lines=200):
     return text.replace("&", "&amp;").replace("<", "&lt;").replace(">", "&gt;")
 
 
+_LOG_SUFFIX = {"infolog": ".log", "debuglog": "_debug.log", "errorlog": "_error.log"}
+
+
 @app.route("/scenario/<scenario_name>/node/<int:idx>/<kind>")
 def fedstellar_monitoring_log(scenario_name, idx, kind):
+    """Whole log file of a node as a download: .../infolog, .../debuglog, .../errorlog
+    (reference app.py:443-453,479-500)."""
+    if "user" not in session:
+        return abort(401)
     _safe(scenario_name)
-    suffix = {"infolog": ".log", "debuglog": "_debug.log", "errorlog": "_error.log"}.get(kind)
+    suffix = _LOG_SUFFIX.get(kind)
     if suffix is None:
         return abort(404)
-    text = _tail(os.path.join(app.config["log_dir"], scenario_name, f"participant_{idx}{suffix}"))
-    if text is None:
+    path = os.path.join(app.config["log_dir"], scenario_name, f"participant_{idx}{suffix}")
+    if not os.path.exists(path):
         return abort(404)
-    return "<pre>" + text + "</pre>"
+    return send_file(path, mimetype="text/plain", as_attachment=True)
+
+
+@app.route("/scenario/<scenario_name>/node/<int:idx>/infolog/<int:number>")
+def fedstellar_monitoring_log_x(scenario_name, idx, number):
+    """Last ``number`` lines of a node's log, ANSI colours stripped and HTML-escaped (the live tail of
+    the monitoring page, reference app.py:455-476)."""
+    if "user" not in session:
+        return abort(401)
+    text = _tail(os.path.join(app.config["log_dir"], _safe(scenario_name), f"participant_{idx}.log"),
+                 max(1, min(int(number), 10000)))
+    return app.response_class("No logs available" if text is None else text, mimetype="text/plain")
+
+
+@app.route("/scenario/<scenario_name>/node/<uid>/update/logs", methods=["POST"])
+def fedstellar_update_node_logs(scenario_name, uid):
+    """Log push from a node that cannot share the log directory (commented out in the reference,
+    app.py:407-416): the body is appended to ``<log_dir>/<scenario>/remote_<uid>.log``."""
+    _safe(scenario_name), _safe(uid)
+    d = os.path.join(app.config["log_dir"], scenario_name)
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, f"remote_{uid}.log"), "a") as f:
+        f.write(request.get_data(as_text=True)[:1 << 20])
+    return "Logs received successfully", 200
+
+
+@app.route("/logs", methods=["GET"])
+def fedstellar_logs():
+    """Controller / server log (reference app.py:418-427)."""
+    if "user" not in session:
+        return abort(401)
+    path = os.path.join(app.config["log_dir"], "server.log")
+    return send_file(path, mimetype="text/plain") if os.path.exists(path) else abort(404)
+
+
+@app.route("/logs/erase", methods=["GET"])
+def fedstellar_logs_erase():
+    if "user" not in session:
+        return abort(401)
+    path = os.path.join(app.config["log_dir"], "server.log")
+    if not os.path.exists(path):
+        return abort(404)
+    with open(path, "w") as f:
+        f.write("Fedstellar Core Logs\n")
+    return redirect(url_for("fedstellar_logs"))
 
 
 @app.route("/scenario/<scenario_name>/topology/image/")

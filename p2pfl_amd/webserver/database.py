@@ -35,6 +35,7 @@ def init_db():
     with _lock, _conn() as c:
         c.execute("CREATE TABLE IF NOT EXISTS users (user TEXT PRIMARY KEY, password TEXT NOT NULL, role TEXT NOT NULL)")
         c.execute("CREATE TABLE IF NOT EXISTS notes (id TEXT PRIMARY KEY, user TEXT, timestamp TEXT, note TEXT)")
+        c.execute("CREATE TABLE IF NOT EXISTS images (uid TEXT PRIMARY KEY, owner TEXT, name TEXT, timestamp TEXT)")
         c.execute("CREATE TABLE IF NOT EXISTS nodes (uid TEXT PRIMARY KEY, idx TEXT, ip TEXT, port TEXT, role TEXT, "
                   "neighbors TEXT, latitude TEXT, longitude TEXT, timestamp TEXT, federation TEXT, scenario TEXT)")
         c.execute("CREATE TABLE IF NOT EXISTS scenarios (name TEXT PRIMARY KEY, start_time TEXT, end_time TEXT, "
@@ -78,6 +79,7 @@ def delete_user_from_db(user):
     with _lock, _conn() as c:
         c.execute("DELETE FROM users WHERE user = ?", (user.upper(),))
         c.execute("DELETE FROM notes WHERE user = ?", (user.upper(),))
+        c.execute("DELETE FROM images WHERE owner = ?", (user.upper(),))
 
 
 # ---------------------------------------------------------------- notes
@@ -103,6 +105,34 @@ def write_note_into_db(user, note):
 def delete_note_from_db(note_id):
     with _lock, _conn() as c:
         c.execute("DELETE FROM notes WHERE id = ?", (note_id,))
+
+
+# ---------------------------------------------------------------- images (reference database.py:176-236)
+def image_upload_record(uid, owner, image_name, timestamp):
+    with _lock, _conn() as c:
+        c.execute("INSERT INTO images VALUES (?, ?, ?, ?)", (uid, owner.upper(), image_name, timestamp))
+
+
+def list_images_for_user(owner):
+    with _conn() as c:
+        return c.execute("SELECT uid, timestamp, name FROM images WHERE owner = ?", (owner.upper(),)).fetchall()
+
+
+def match_user_id_with_image_uid(image_uid):
+    with _conn() as c:
+        row = c.execute("SELECT owner FROM images WHERE uid = ?", (image_uid,)).fetchone()
+    return row[0] if row else None
+
+
+def get_image_file_name(image_uid):
+    with _conn() as c:
+        row = c.execute("SELECT name FROM images WHERE uid = ?", (image_uid,)).fetchone()
+    return None if row is None else f"{image_uid}-{row[0]}"
+
+
+def delete_image_from_db(image_uid):
+    with _lock, _conn() as c:
+        c.execute("DELETE FROM images WHERE uid = ?", (image_uid,))
 
 
 # ---------------------------------------------------------------- nodes

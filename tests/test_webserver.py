@@ -114,13 +114,27 @@ def test_logs_statistics_and_download(web):
     (ldir / "participant_0.log").write_text("\x1b[32mline <one>\x1b[0m\nline two\n")
     (ldir / "metrics" / "participant_0" / "metrics.csv").write_text(
         "time,step,name,value\n1.0,0,Test/Loss,2.3\n2.0,1,Test/Loss,1.1\n2.0,1,TestEpoch/Accuracy,0.8\n")
-    r = c.get(f"/scenario/{name}/node/0/infolog")
-    assert r.status_code == 200 and b"line &lt;one&gt;" in r.data and b"\x1b" not in r.data
-    assert c.get(f"/scenario/{name}/node/0/errorlog").status_code == 404
-    assert c.get(f"/scenario/{name}/node/0/other").status_code == 404
+    assert c.get(f"/scenario/{name}/node/0/infolog").status_code == 401
     m = c.get(f"/api/scenario/{name}/statistics/").get_json()
     assert m["participant_0"]["Test/Loss"] == [[0, 2.3], [1, 1.1]]
     _login(c)
+    r = c.get(f"/scenario/{name}/node/0/infolog")          # whole file, as a download
+    assert r.status_code == 200 and r.data.endswith(b"line two\n") and "attachment" in r.headers["Content-Disposition"]
+    r = c.get(f"/scenario/{name}/node/0/infolog/1")        # live tail: last n lines, ANSI stripped, escaped
+    assert r.status_code == 200 and r.data == b"line two\n"
+    r = c.get(f"/scenario/{name}/node/0/infolog/50")
+    assert b"line &lt;one&gt;" in r.data and b"\x1b" not in r.data
+    assert c.get(f"/scenario/{name}/node/7/infolog/5").data == b"No logs available"
+    assert c.get(f"/scenario/{name}/node/0/errorlog").status_code == 404
+    assert c.get(f"/scenario/{name}/node/0/other").status_code == 404
+    # log push from a remote node + controller log view / erase
+    assert c.post(f"/scenario/{name}/node/abc123/update/logs", data="remote line\n").status_code == 200
+    assert (ldir / "remote_abc123.log").read_text() == "remote line\n"
+    assert c.get("/logs").status_code == 404
+    (tmp / "logs" / "server.log").write_text("controller says hi\n")
+    assert c.get("/logs").data == b"controller says hi\n"
+    assert c.get("/logs/erase").status_code == 302
+    assert (tmp / "logs" / "server.log").read_text().startswith("Fedstellar Core Logs")
     assert b"TestEpoch/Accuracy" in c.get(f"/scenario/{name}/statistics/").data
     z = c.get(f"/scenario/{name}/statistics/download")
     assert z.status_code == 200
@@ -159,3 +173,28 @@ def test_deployment_run_builds_scenario_and_calls_launcher(web, monkeypatch):
     assert started["n"] == 3 and appmod.db.get_running_scenario()[0] == name
     assert c.get(f"/scenario/{name}/remove").status_code == 302
     assert appmod.db.get_scenario_by_name(name) is None and not cdir.exists()
+
+
+def test_image_upload_view_delete(web):
+    appmod, c, tmp = web
+    png = b"\x89PNG\r\n\x1a\n" + b"0" * 32
+    assert c.post("/upload_image", data={"file": (io.BytesIO(png), "plot.png")}).status_code == 401
+    _login(c)
+    assert c.post("/upload_image", data={"file": (io.BytesIO(png), "plot.png")},
+                  content_type="multipart/form-data").status_code == 302
+    assert c.post("/upload_image", data={"file": (io.BytesIO(b"x"), "evil.sh")},
+                  content_type="multipart/form-data").status_code == 302          # ignored: extension not allowed
+    imgs = appmod.db.list_images_for_user("admin")
+    assert len(imgs) == 1 and imgs[0][2] == "plot.png"
+    uid = imgs[0][0]
+    assert b"plot.png" in c.get("/scenario/x/private/").data
+    assert c.get(f"/images/{uid}/").data == png
+    # another user cannot see or delete it
+    c.post("/add_user", data={"user": "bob", "password": "pw", "role": "user"})
+    c.get("/logout/")
+    _login(c, "bob", "pw")
+    assert c.get(f"/images/{uid}/").status_code == 401 and c.get(f"/delete_image/{uid}").status_code == 401
+    c.get("/logout/")
+    _login(c)
+    assert c.get(f"/delete_image/{uid}").status_code == 302
+    assert appmod.db.list_images_for_user("admin") == [] and c.get(f"/images/{uid}/").status_code == 401

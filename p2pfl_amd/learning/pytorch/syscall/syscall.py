@@ -2,13 +2,22 @@
 (reference: fedstellar/learning/pytorch/syscall/syscall.py:21-218).
 
 17 scaled 1-gram system-call frequency features, 9 classes, 85/15 train/test split, validation =
-1 % of the shard (syscall.py:60-112,139-181). The reference downloads a zip of CSVs; here
-``syscall.pt`` (``(x_train, y_train, x_test, y_test)`` tensors, ``weights_only=True``) or
-``syscall.csv`` (17 feature columns + label column) under ``root_dir`` are used when present,
-otherwise a synthetic set of the same shape.
+1 % of the shard (syscall.py:60-112,139-181). The reference downloads a zip of CSVs (no network here);
+looked up under ``root_dir``, in this order:
+
+* ``syscall.pt`` - ``(x_train, y_train, x_test, y_test)`` tensors (``weights_only=True``);
+* ``raw/*.csv``  - the reference's raw files: tab-separated, column ``system calls frequency_1gram-scaled``
+  holding a Python list literal per row and the class name in ``maltype`` (``normalv2`` is folded into
+  ``normal``), processed exactly like ``SYSCALL.process`` (syscall.py:74-112): 85/15
+  ``train_test_split(random_state=42)``; classes are numbered in sorted name order (the reference numbers
+  them in ``set()`` iteration order, which changes from run to run);
+* ``syscall.csv`` - plain numeric CSV, 17 feature columns + label column;
+* otherwise a synthetic set of the same shape.
 """
 from __future__ import annotations
 
+import ast
+import glob
 import logging
 import os
 
@@ -17,7 +26,29 @@ import torch
 from ..datamodule import FederatedDataModule, synthetic_classification
 
 
+FEATURE = "system calls frequency_1gram-scaled"
+
+
+def process_raw_csvs(files):
+    """Reference ``SYSCALL.process`` on its raw CSV files -> (x_train, y_train, x_test, y_test, classes)."""
+    import csv as _csv
+    feats, names = [], []
+    for path in files:
+        with open(path, newline="") as f:
+            for row in _csv.DictReader(f, delimiter="\t"):
+                feats.append([float(v) for v in ast.literal_eval(row[FEATURE])])
+                names.append("normal" if row["maltype"] == "normalv2" else row["maltype"])
+    classes = sorted(set(names))
+    index = {c: i for i, c in enumerate(classes)}
+    x = torch.tensor(feats, dtype=torch.float32)
+    y = torch.tensor([index[n] for n in names], dtype=torch.long)
+    from sklearn.model_selection import train_test_split
+    itr, ite = train_test_split(list(range(len(x))), test_size=0.15, random_state=42)
+    return x[itr], y[itr], x[ite], y[ite], classes
+
+
 class SYSCALLDataModule(FederatedDataModule):
+    classes = None
     num_classes = 9
     input_shape = (17,)
     train_set = None
@@ -37,6 +68,9 @@ class SYSCALLDataModule(FederatedDataModule):
         pt, csv = os.path.join(root, "syscall.pt"), os.path.join(root, "syscall.csv")
         if os.path.exists(pt):
             tx, ty, ex, ey = torch.load(pt, weights_only=True)
+            cls.synthetic = False
+        elif glob.glob(os.path.join(root, "raw", "*.csv")):
+            tx, ty, ex, ey, cls.classes = process_raw_csvs(sorted(glob.glob(os.path.join(root, "raw", "*.csv"))))
             cls.synthetic = False
         elif os.path.exists(csv):
             import numpy as np

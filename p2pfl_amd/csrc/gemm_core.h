@@ -33,7 +33,7 @@ __device__ __forceinline__ int mfma_row(int reg, int lane) {
     return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
 }
 
-// PERM4 (ROWS == 128 only): LDS row rho holds global row 4*(rho & 31) + (rho >> 5). With four
+// PERM4 (ROWS % 128 == 0; per 128-row block): LDS row rho holds global row 4*(rho & 31) + (rho >> 5). With four
 // 32-column MFMA tiles per wave this puts output columns 4r..4r+3 into the four accumulators of
 // lane r, so an epilogue can move float4 (16 B) per lane along the contiguous output dimension.
 template <int ROWS, int NT, class Loader, bool PERM4 = false>
@@ -52,7 +52,7 @@ struct TileStager {
             int c = threadIdx.x + i * NT;
             if (CHUNKS % NT == 0 || c < CHUNKS) {
                 int row, k8; decode(c, row, k8);
-                if (PERM4) row = 4 * (row & 31) + (row >> 5);
+                if (PERM4) row = (row & ~127) + 4 * (row & 31) + ((row & 127) >> 5);
                 ld.load8(row0 + row, k0 + k8 * 8, v[i]);
             }
         }
@@ -69,18 +69,21 @@ struct TileStager {
     }
 };
 
-template <int BM, int BN>
+// NBUF = 2: double-buffered staging (one barrier per k-step). NBUF = 1: a single buffer (two barriers
+// per k-step) for products whose reduction is one or two k-steps deep, where the second buffer would
+// only cost occupancy (weight gradients: k = batch = 32).
+template <int BM, int BN, int NBUF = 2>
 struct GemmSmem {
-    __bf16 a[2][BM * GEMM_LDK];
-    __bf16 b[2][BN * GEMM_LDK];
+    __bf16 a[NBUF][BM * GEMM_LDK];
+    __bf16 b[NBUF][BN * GEMM_LDK];
 };
 
 // Runs one BM x BN block tile over k in [k_begin, k_end) (k_begin % 32 == 0; loaders
 // zero-fill past their own K extent). All threads of the block must call it.
-// N4 = true (needs BN == 128, WC == 1): B is staged with the PERM4 row permutation and the epilogue
+// N4 = true (needs 128-column wave tiles, BN = 128 * WC): B is staged with the PERM4 row permutation and the epilogue
 // is called as  epi.store4(float4 v, int m, int n)  with v = C[m][n .. n+3], n % 4 == 0.
-template <int BM, int BN, int WR, int WC, class AL, class BL, class EPI, bool N4 = false>
-__device__ __forceinline__ void gemm_block_tile(GemmSmem<BM, BN>& sm, const AL& al, const BL& bl,
+template <int BM, int BN, int WR, int WC, class AL, class BL, class EPI, bool N4 = false, int NBUF = 2>
+__device__ __forceinline__ void gemm_block_tile(GemmSmem<BM, BN, NBUF>& sm, const AL& al, const BL& bl,
                                                 const EPI& epi, int m0, int n0, int k_begin,
                                                 int k_end) {
     constexpr int NT = 64 * WR * WC;
@@ -103,7 +106,7 @@ __device__ __forceinline__ void gemm_block_tile(GemmSmem<BM, BN>& sm, const AL& 
 
     TileStager<BM, NT, AL> sa;
     TileStager<BN, NT, BL, N4> sb;
-    static_assert(!N4 || (BN == 128 && WC == 1), "N4 epilogue needs one 128-column wave tile");
+    static_assert(!N4 || TN == 128, "N4 epilogue needs 128-column wave tiles");
 
     sa.load(al, m0, k_begin);
     sb.load(bl, n0, k_begin);
@@ -135,12 +138,21 @@ __device__ __forceinline__ void gemm_block_tile(GemmSmem<BM, BN>& sm, const AL& 
                 for (int j = 0; j < RN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        if (has_next) {
-            sa.store(sm.a[cur ^ 1]);
-            sb.store(sm.b[cur ^ 1]);
+        if constexpr (NBUF == 2) {
+            if (has_next) {
+                sa.store(sm.a[cur ^ 1]);
+                sb.store(sm.b[cur ^ 1]);
+            }
+            __syncthreads();
+            cur ^= 1;
+        } else {
+            if (has_next) {
+                __syncthreads();          // every wave is done reading the only buffer
+                sa.store(sm.a[0]);
+                sb.store(sm.b[0]);
+                __syncthreads();
+            }
         }
-        __syncthreads();
-        cur ^= 1;
     }
 
     if constexpr (N4) {
@@ -149,7 +161,7 @@ __device__ __forceinline__ void gemm_block_tile(GemmSmem<BM, BN>& sm, const AL& 
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 epi.store4(make_float4(acc[i][0][e], acc[i][1][e], acc[i][2][e], acc[i][3][e]),
-                           m0 + wr * TM + i * 32 + mfma_row(e, lane), n0 + 4 * r);
+                           m0 + wr * TM + i * 32 + mfma_row(e, lane), n0 + wc * TN + 4 * r);
     } else {
 #pragma unroll
         for (int i = 0; i < RM; ++i)

@@ -8,10 +8,12 @@
 // v_mfma_f32_32x32x16_bf16 (fp32 accumulate) and handed tile-by-tile to an
 // *epilogue functor* (bias/ReLU/pool/optimizer fusions live there).
 //
-// Geometry (64-lane waves):  block = WR x WC waves, block tile BM x BN, BK = 32.
+// Geometry (64-lane waves):  block = WR x WC waves, block tile BM x BN, BK = 32 (default; 64 / 128 for
+// weight-streaming products with a long reduction, where a 32-deep step is latency- not bandwidth-bound).
 // Each wave owns (BM/WR) x (BN/WC) outputs = RM x RN tiles of 32x32.
-// LDS rows hold 32 bf16 + 8 pad (80 B): every 16-lane ds_read_b128 group lands on 16
-// distinct 16-B slots of the 256-B bank row, so fragment reads are conflict-free.
+// LDS rows hold BK bf16 + 8 pad (80 / 144 / 272 B = an odd multiple of 16 B): every 16-lane
+// ds_read_b128 group lands on 16 distinct 16-B slots of the 256-B bank row, so fragment reads are
+// conflict-free.
 // Staging is register-split (issue global loads for tile t+1, run the MFMAs of tile t,
 // then write t+1 into the other LDS buffer): one barrier per K-step.
 //
@@ -36,15 +38,17 @@ __device__ __forceinline__ int mfma_row(int reg, int lane) {
 // PERM4 (ROWS % 128 == 0; per 128-row block): LDS row rho holds global row 4*(rho & 31) + (rho >> 5). With four
 // 32-column MFMA tiles per wave this puts output columns 4r..4r+3 into the four accumulators of
 // lane r, so an epilogue can move float4 (16 B) per lane along the contiguous output dimension.
-template <int ROWS, int NT, class Loader, bool PERM4 = false>
+template <int ROWS, int NT, class Loader, bool PERM4 = false, int BK = GEMM_BK>
 struct TileStager {
-    static constexpr int CHUNKS = ROWS * 4;                    // 16-B (8 x bf16) chunks per tile
+    static constexpr int KC = BK / 8;                          // chunks per row
+    static constexpr int LDK = BK + 8;
+    static constexpr int CHUNKS = ROWS * KC;                   // 16-B (8 x bf16) chunks per tile
     static constexpr int PER_THREAD = (CHUNKS + NT - 1) / NT;  // chunks each thread moves
     float v[PER_THREAD][8];
 
     __device__ __forceinline__ static void decode(int c, int& row, int& k8) {
         if (Loader::ROW_CONTIG) { row = c % ROWS; k8 = c / ROWS; }
-        else                    { row = c >> 2;   k8 = c & 3; }
+        else                    { row = c / KC;   k8 = c % KC; }
     }
     __device__ __forceinline__ void load(const Loader& ld, int row0, int k0) {
 #pragma unroll
@@ -63,7 +67,7 @@ struct TileStager {
             int c = threadIdx.x + i * NT;
             if (CHUNKS % NT == 0 || c < CHUNKS) {
                 int row, k8; decode(c, row, k8);
-                *reinterpret_cast<bf16x8*>(lds + row * GEMM_LDK + k8 * 8) = pack_bf16x8(v[i]);
+                *reinterpret_cast<bf16x8*>(lds + row * LDK + k8 * 8) = pack_bf16x8(v[i]);
             }
         }
     }
@@ -72,21 +76,23 @@ struct TileStager {
 // NBUF = 2: double-buffered staging (one barrier per k-step). NBUF = 1: a single buffer (two barriers
 // per k-step) for products whose reduction is one or two k-steps deep, where the second buffer would
 // only cost occupancy (weight gradients: k = batch = 32).
-template <int BM, int BN, int NBUF = 2>
+template <int BM, int BN, int NBUF = 2, int BK = GEMM_BK>
 struct GemmSmem {
-    __bf16 a[NBUF][BM * GEMM_LDK];
-    __bf16 b[NBUF][BN * GEMM_LDK];
+    __bf16 a[NBUF][BM * (BK + 8)];
+    __bf16 b[NBUF][BN * (BK + 8)];
 };
 
 // Runs one BM x BN block tile over k in [k_begin, k_end) (k_begin % 32 == 0; loaders
-// zero-fill past their own K extent). All threads of the block must call it.
+// zero-fill past their own K extent; k_begin % BK == 0). All threads of the block must call it.
 // N4 = true (needs 128-column wave tiles, BN = 128 * WC): B is staged with the PERM4 row permutation and the epilogue
 // is called as  epi.store4(float4 v, int m, int n)  with v = C[m][n .. n+3], n % 4 == 0.
-template <int BM, int BN, int WR, int WC, class AL, class BL, class EPI, bool N4 = false, int NBUF = 2>
-__device__ __forceinline__ void gemm_block_tile(GemmSmem<BM, BN, NBUF>& sm, const AL& al, const BL& bl,
+template <int BM, int BN, int WR, int WC, class AL, class BL, class EPI, bool N4 = false, int NBUF = 2,
+          int BK = GEMM_BK>
+__device__ __forceinline__ void gemm_block_tile(GemmSmem<BM, BN, NBUF, BK>& sm, const AL& al, const BL& bl,
                                                 const EPI& epi, int m0, int n0, int k_begin,
                                                 int k_end) {
     constexpr int NT = 64 * WR * WC;
+    constexpr int LDK = BK + 8;
     constexpr int TM = BM / WR, TN = BN / WC;
     constexpr int RM = TM / 32, RN = TN / 32;
     static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of 32x32");
@@ -104,8 +110,8 @@ __device__ __forceinline__ void gemm_block_tile(GemmSmem<BM, BN, NBUF>& sm, cons
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    TileStager<BM, NT, AL> sa;
-    TileStager<BN, NT, BL, N4> sb;
+    TileStager<BM, NT, AL, false, BK> sa;
+    TileStager<BN, NT, BL, N4, BK> sb;
     static_assert(!N4 || TN == 128, "N4 epilogue needs 128-column wave tiles");
 
     sa.load(al, m0, k_begin);
@@ -115,23 +121,23 @@ __device__ __forceinline__ void gemm_block_tile(GemmSmem<BM, BN, NBUF>& sm, cons
     __syncthreads();
 
     int cur = 0;
-    for (int k = k_begin; k < k_end; k += GEMM_BK) {
-        const bool has_next = (k + GEMM_BK) < k_end;
+    for (int k = k_begin; k < k_end; k += BK) {
+        const bool has_next = (k + BK) < k_end;
         if (has_next) {
-            sa.load(al, m0, k + GEMM_BK);
-            sb.load(bl, n0, k + GEMM_BK);
+            sa.load(al, m0, k + BK);
+            sb.load(bl, n0, k + BK);
         }
-        const __bf16* as = sm.a[cur] + (wr * TM + r) * GEMM_LDK + h * 8;
-        const __bf16* bs = sm.b[cur] + (wc * TN + r) * GEMM_LDK + h * 8;
+        const __bf16* as = sm.a[cur] + (wr * TM + r) * LDK + h * 8;
+        const __bf16* bs = sm.b[cur] + (wc * TN + r) * LDK + h * 8;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BK / 16; ++kk) {
             bf16x8 af[RM], bfr[RN];
 #pragma unroll
             for (int i = 0; i < RM; ++i)
-                af[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * GEMM_LDK + kk * 16);
+                af[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * LDK + kk * 16);
 #pragma unroll
             for (int j = 0; j < RN; ++j)
-                bfr[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * GEMM_LDK + kk * 16);
+                bfr[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * LDK + kk * 16);
 #pragma unroll
             for (int i = 0; i < RM; ++i)
 #pragma unroll

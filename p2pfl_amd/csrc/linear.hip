@@ -37,15 +37,17 @@ struct EpiBiasAct {
 };
 
 // y = act(x W^T + b);  M = B, N = Out, K = In
+template <int BK, int NBUF>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(LinearArgs a) {
-    __shared__ GemmSmem<32, 128> sm;
+    __shared__ GemmSmem<32, 128, NBUF, BK> sm;
     const int c = blockIdx.z;
     const float* x = a.x + c * a.x_cs;
     const float* w = a.w + c * a.w_cs;
     LoadRowMajorK al{x, a.B, a.In, a.In, (bool)(a.vec & 1)};
     LoadRowMajorK bl{w, a.Out, a.In, a.In, (bool)(a.vec & 2)};
     EpiBiasAct epi{a.y + c * a.y_cs, a.b + c * a.b_cs, a.B, a.Out, a.relu};
-    gemm_block_tile<32, 128, 1, 4>(sm, al, bl, epi, blockIdx.y * 32, blockIdx.x * 128, 0, a.In);
+    gemm_block_tile<32, 128, 1, 4, LoadRowMajorK, LoadRowMajorK, EpiBiasAct, false, NBUF, BK>(
+        sm, al, bl, epi, blockIdx.y * 32, blockIdx.x * 128, 0, a.In);
 }
 
 struct DgradArgs {
@@ -75,13 +77,15 @@ struct EpiMaskStore {
 };
 
 // dx = (dy W) * [act > 0];  M = B, N = In, K = Out
+template <int BK, int NBUF>
 __global__ __launch_bounds__(256) void linear_dgrad_kernel(DgradArgs a) {
-    __shared__ GemmSmem<32, 128> sm;
+    __shared__ GemmSmem<32, 128, NBUF, BK> sm;
     const int c = blockIdx.z;
     LoadRowMajorK al{a.dy + c * a.dy_cs, a.B, a.Out, a.Out, (bool)a.vec};
     LoadColMajorK bl{a.w + c * a.w_cs, a.In, a.Out, a.In};
     EpiMaskStore epi{a.dx + c * a.dx_cs, a.act ? a.act + c * a.act_cs : nullptr, a.B, a.In};
-    gemm_block_tile<32, 128, 1, 4>(sm, al, bl, epi, blockIdx.y * 32, blockIdx.x * 128, 0, a.Out);
+    gemm_block_tile<32, 128, 1, 4, LoadRowMajorK, LoadColMajorK, EpiMaskStore, false, NBUF, BK>(
+        sm, al, bl, epi, blockIdx.y * 32, blockIdx.x * 128, 0, a.Out);
 }
 
 struct WgradArgs {
@@ -263,7 +267,10 @@ P2PFL_API int p2pfl_linear_fwd(const float* x, long x_cs, const float* w, long w
     const int wv = !((In & 3) || (w_cs & 3) || ((uintptr_t)w & 15));
     LinearArgs a{x, x_cs, w, w_cs, b, b_cs, y, y_cs, B, In, Out, relu, xv | (wv << 1)};
     dim3 grid(cdiv(Out, 128), cdiv(B, 32), K);
-    hipLaunchKernelGGL(linear_fwd_kernel, grid, dim3(256), 0, stream, a);
+    // long reductions (MNIST-CNN l1: In = 3136) take 64-deep k-steps: half the barriers / twice the bytes in
+    // flight per step (100 clients on MI355X: 546 -> 516 us; 128-deep steps cost occupancy: 514-589 us)
+    if (In >= 1024) hipLaunchKernelGGL((linear_fwd_kernel<64, 2>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((linear_fwd_kernel<32, 2>), grid, dim3(256), 0, stream, a);
     P2PFL_RETURN_LAST_ERROR();
 }
 
@@ -275,7 +282,8 @@ P2PFL_API int p2pfl_linear_dgrad(const float* dy, long dy_cs, const float* w, lo
     const int vec = !((Out & 3) || (dy_cs & 3) || ((uintptr_t)dy & 15));
     DgradArgs a{dy, dy_cs, w, w_cs, act, act_cs, dx, dx_cs, B, In, Out, vec};
     dim3 grid(cdiv(In, 128), cdiv(B, 32), K);
-    hipLaunchKernelGGL(linear_dgrad_kernel, grid, dim3(256), 0, stream, a);
+    if (Out >= 1024) hipLaunchKernelGGL((linear_dgrad_kernel<64, 2>), grid, dim3(256), 0, stream, a);   // 498 -> 478 us
+    else hipLaunchKernelGGL((linear_dgrad_kernel<32, 2>), grid, dim3(256), 0, stream, a);
     P2PFL_RETURN_LAST_ERROR();
 }
 

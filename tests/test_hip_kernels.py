@@ -301,3 +301,25 @@ def test_aes128_ecb_known_answer_and_roundtrip():
     h.aes128_ecb(e2, d2, rk, decrypt=True)
     assert (d2 == big).all()
     assert bytes(e2[:4096].cpu().tolist()) == ecb_host(key, bytes(big[:4096].cpu().tolist()), decrypt=False)
+
+
+@pytest.mark.parametrize("In,Out", [(1024, 96), (1100, 70)])
+def test_linear_long_reduction_variants(In, Out):
+    """In / Out >= 1024 dispatch to the 64-deep k-step kernels (incl. a ragged last step)."""
+    from p2pfl_amd.ops import hip
+    torch.manual_seed(1)
+    K, B = 2, 32
+    x = torch.randn(K, B, In, device="cuda")
+    w = torch.randn(K, Out, In, device="cuda") * 0.05
+    b = torch.randn(K, Out, device="cuda")
+    y = torch.empty(K, B, Out, device="cuda")
+    hip.linear_fwd(x, w, b, y, False)
+    ref = torch.einsum("kbi,koi->kbo", x, w) + b[:, None]
+    assert ((y - ref).norm() / ref.norm()).item() < 6e-3
+    # data gradient with the roles of In / Out swapped: the reduction runs over `Out2 = In`
+    dy = torch.randn(K, B, In, device="cuda")
+    w2 = torch.randn(K, In, Out, device="cuda") * 0.05
+    dx = torch.empty(K, B, Out, device="cuda")
+    hip.linear_dgrad(dy, w2, None, dx)
+    refd = torch.einsum("kbo,koi->kbi", dy, w2)
+    assert ((dx - refd).norm() / refd.norm()).item() < 6e-3

@@ -198,3 +198,24 @@ def test_image_upload_view_delete(web):
     _login(c)
     assert c.get(f"/delete_image/{uid}").status_code == 302
     assert appmod.db.list_images_for_user("admin") == [] and c.get(f"/images/{uid}/").status_code == 401
+
+
+def test_pages_render_with_bundled_scripts(web):
+    """The designer / monitoring / statistics pages use only scripts shipped in static/ (no CDN: the
+    target machines have no network)."""
+    appmod, c, tmp = web
+    _login(c)
+    page = c.get("/scenario/deployment/").data.decode()
+    assert "js/graph.js" in page and "TopologyGraph.generate" in page and "http://" not in page.replace("http://www.w3.org", "")
+    for path in ("/static/js/graph.js", "/static/js/charts.js", "/static/style.css"):
+        r = c.get(path)
+        assert r.status_code == 200 and len(r.data) > 200
+    name = "scen2"
+    appmod.db.scenario_update_record(name, "now", "", "t", "d", "running", "")
+    appmod.db.update_node_record("u0", 0, "127.0.0.1", 46000, "aggregator", "127.0.0.1:46001", 40.4, -3.7,
+                                 datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S.%f"), "DFL", name)
+    mon = c.get(f"/scenario/{name}/monitoring").data.decode()
+    assert "geoMap" in mon and f"/scenario/{name}/node/" in mon and "infolog/40" in mon
+    d = c.get(f"/api/scenario/{name}/monitoring").get_json()
+    assert d["nodes_table"][0]["latitude"] == "40.4"
+    assert b"lineChart" in c.get(f"/scenario/{name}/statistics/").data

@@ -6,8 +6,11 @@ Semantics kept:
   it when a contributor is already present, returns the flattened list of contributors held (the
   ``MODELS_AGGREGATED`` broadcast) or None; the first model of a round arms the
   ``AGGREGATION_TIMEOUT`` (aggregator.py:106-179);
-* in *waiting* mode every received model is adopted immediately (``AGGREGATION_FINISHED_EVENT``,
-  aggregator.py:119-123);
+* in *waiting* mode a received model is adopted immediately (``AGGREGATION_FINISHED_EVENT``,
+  aggregator.py:119-123) - restricted here to *complete* models (a diffused final model, or an aggregate
+  whose contributors cover this node's train set): the reference adopts anything, so an SDFL trainer
+  could end a round with another trainer's raw model. Partial aggregates that reach a waiting node are
+  kept like on a non-waiting one (that is also what a PROXY relays);
 * ``get_partial_aggregation(except_nodes)`` aggregates the stored entries disjoint from what a peer
   already holds -> ``(model, contributors, summed weight)`` (aggregator.py:181-208);
 * aggregation runs when the contributors cover the train set, on ``force``, or at the timeout with
@@ -122,7 +125,7 @@ class Aggregator(Observable):
         """``check=False`` defers the completeness check: the caller announces the new contributor set
         (MODELS_AGGREGATED) first and then calls :meth:`check_and_run_aggregation` itself, so that a
         peer never sees this round's MODELS_READY before the last MODELS_AGGREGATED."""
-        if self._waiting_aggregated_model:
+        if self._waiting_aggregated_model and self.is_complete(nodes):
             logging.info("[Aggregator] received a model from %s while waiting -> adopting it", nodes)
             self.notify(Events.AGGREGATION_FINISHED_EVENT, model)
             self._done.set()
@@ -144,6 +147,15 @@ class Aggregator(Observable):
                     return models_added + list(nodes)
                 logging.debug("[Aggregator] can't add a model that has already been added %s", nodes)
         return None
+
+    def is_complete(self, nodes) -> bool:
+        """A model a waiting node may adopt as the round's result: diffused (no contributor list) or
+        aggregated from at least this node's whole train set (an empty train set accepts anything:
+        IDLE / PROXY nodes)."""
+        if nodes is None:
+            return True
+        with self._lock:
+            return set(self._train_set) <= set(nodes)
 
     def get_partial_aggregation(self, except_nodes):
         with self._lock:

@@ -259,8 +259,8 @@ class Node(BaseNode):
                     # a model for a round we have not contributed to yet: the reference's non-waiting
                     # aggregator ignores it too (aggregator.py:177-178)
                     return
-                early_aggregate = waits and not self.aggregator.get_waiting_aggregated_model() and (
-                    contributors is None or (self.get_name() in contributors and len(contributors) > 1))
+                early_aggregate = (waits and not self.aggregator.get_waiting_aggregated_model()
+                                   and self.aggregator.is_complete(contributors))
                 if early_aggregate:
                     # the aggregate overtook our own "waiting" transition: adopt it now
                     self.update(Events.AGGREGATION_FINISHED_EVENT, decoded)
@@ -308,6 +308,10 @@ class Node(BaseNode):
                     self._gossip_model_aggregation()
                 # do not advance before the aggregate was adopted (reference race)
                 self._aggregation_done.wait(float(self._p("AGGREGATION_TIMEOUT")) + 5.0)
+                if role == Role.AGGREGATOR and self._p("scenario_args").get("federation", "DFL") != "DFL":
+                    # SDFL / mixed-role scenarios: neighbours in waiting roles take this node's result
+                    # (the reference leaves them with whatever payload arrived first, aggregator.py:119-123)
+                    self._gossip_model_difusion()
 
         elif role == Role.TRAINER:
             self.aggregator.set_nodes_to_aggregate(self._train_set)

@@ -105,3 +105,63 @@ def test_connections_refused_while_learning_and_dead_neighbor_eviction():
         assert nodes[0].get_neighbors() == []          # END_CONNECTION -> rm_neighbor
     finally:
         stop_all(nodes)
+
+
+def test_sdfl_leadership_moves_over_tcp():
+    """SDFL: node 0 starts as the only aggregator; after every round the role is handed to a random
+    neighbour with TRANSFER_LEADERSHIP (reference node.py:648-650,676-686; command.py:161-167)."""
+    nodes = make_nodes(3, [Role.AGGREGATOR, Role.TRAINER, Role.TRAINER], federation="SDFL")
+    try:
+        for i in range(3):
+            for j in range(i + 1, 3):
+                assert nodes[i].connect_to(nodes[j].host, nodes[j].port) is not None
+        time.sleep(0.5)
+        seen = []
+        nodes[0].set_start_learning(rounds=3, epochs=1)
+        t0 = time.time()
+        while time.time() - t0 < 120:
+            roles = tuple(n.role for n in nodes)
+            if not seen or seen[-1] != roles:
+                seen.append(roles)
+            if all(n.round is None for n in nodes) and len(seen) > 1:
+                break
+            time.sleep(0.02)
+        assert all(n.round is None for n in nodes)
+        # exactly one aggregator whenever the roles are observed at rest, and it changed hands at least once
+        finals = [n.role for n in nodes]
+        assert finals.count(Role.AGGREGATOR) == 1
+        assert len({r.index(Role.AGGREGATOR) for r in seen if r.count(Role.AGGREGATOR) == 1}) >= 2
+        assert models_equal(nodes[0], nodes[1]) and models_equal(nodes[0], nodes[2])
+    finally:
+        stop_all(nodes)
+
+
+def test_checkpoint_per_round_and_resume(tmp_path):
+    """Per-round checkpoints are the reference payload bytes (+ JSON sidecar); a fresh node resumes from one."""
+    import pickle
+
+    nodes = make_nodes(2, [Role.AGGREGATOR] * 2)
+    try:
+        for n in nodes:
+            n.checkpoint_dir = str(tmp_path)
+        nodes[0].connect_to(nodes[1].host, nodes[1].port)
+        time.sleep(0.5)
+        nodes[0].set_start_learning(rounds=2, epochs=1)
+        assert wait_finished(nodes)
+        files = sorted(p.name for p in tmp_path.glob("*.ckpt"))
+        assert files == ["participant_0_round_1.ckpt", "participant_0_round_2.ckpt",
+                         "participant_1_round_1.ckpt", "participant_1_round_2.ckpt"]
+        # payload format of the reference: pickle((arrays in state_dict order, contributors, weight))
+        arrays, contributors, weight = pickle.loads((tmp_path / files[1]).read_bytes())
+        sd = nodes[0].learner.get_parameters()
+        assert [a.shape for a in arrays] == [tuple(v.shape) for v in sd.values()]
+        assert contributors == [nodes[0].get_name()] and weight == nodes[0].learner.get_num_samples()[0]
+        fresh = make_nodes(1, [Role.AGGREGATOR])[0]
+        try:
+            assert not models_equal(fresh, nodes[0])
+            meta = fresh.load_checkpoint(str(tmp_path / "participant_0_round_2.ckpt"))
+            assert models_equal(fresh, nodes[0]) and meta["node"] == nodes[0].get_name()
+        finally:
+            fresh.stop()
+    finally:
+        stop_all(nodes)

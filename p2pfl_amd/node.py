@@ -255,9 +255,11 @@ class Node(BaseNode):
                     return
                 if self._aggregation_done.is_set():
                     return      # this round's aggregate is already in place: a duplicate must not be re-announced
-                if waits and not self._local_done:
-                    # a model for a round we have not contributed to yet: the reference's non-waiting
-                    # aggregator ignores it too (aggregator.py:177-178)
+                if waits and not self._local_done and self.aggregator.is_complete(contributors):
+                    # the round's result overtook our own training: it cannot replace the model while the
+                    # local fit is running; the sender repeats it until we announce MODELS_READY. Partial
+                    # aggregates ARE kept, so a round without a leader (TRANSFER_LEADERSHIP still in
+                    # flight) completes by every trainer averaging its train set itself.
                     return
                 early_aggregate = (waits and not self.aggregator.get_waiting_aggregated_model()
                                    and self.aggregator.is_complete(contributors))

@@ -128,7 +128,11 @@ def test_sdfl_leadership_moves_over_tcp():
             time.sleep(0.02)
         assert all(n.round is None for n in nodes)
         # exactly one aggregator whenever the roles are observed at rest, and it changed hands at least once
+        t0 = time.time()
+        while [n.role for n in nodes].count(Role.AGGREGATOR) != 1 and time.time() - t0 < 5:
+            time.sleep(0.05)                      # the last TRANSFER_LEADERSHIP may still be on the wire
         finals = [n.role for n in nodes]
+        seen.append(tuple(finals))
         assert finals.count(Role.AGGREGATOR) == 1
         assert len({r.index(Role.AGGREGATOR) for r in seen if r.count(Role.AGGREGATOR) == 1}) >= 2
         assert models_equal(nodes[0], nodes[1]) and models_equal(nodes[0], nodes[2])

@@ -112,10 +112,12 @@ class Aggregator(Observable):
             logging.info("[Aggregator] aggregating with missing models: %s", set(train_set) - set(have))
         result = self.aggregate(models) if models else None
         with self._lock:
+            # delivered under the lock: clear() (round advance) waits for a delivery in progress and a
+            # result of a cleared round is never handed to the next one
             if gen != self._generation:
                 return
-        self.notify(Events.AGGREGATION_FINISHED_EVENT, result)
-        done.set()
+            self.notify(Events.AGGREGATION_FINISHED_EVENT, result)
+            done.set()
 
     def wait_aggregation(self, timeout: Optional[float] = None) -> bool:
         """Block until this round's result was delivered (True) or ``timeout`` elapsed."""

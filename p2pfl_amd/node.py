@@ -290,7 +290,7 @@ class Node(BaseNode):
         self._validate_train_set()
         self._ready_sent = False
         self._local_done = Role.waits(self.role) and not Role.trains(self.role)   # proxy / idle: nothing to do
-        role = self.role
+        role = self._round_role = self.role
 
         if role in (Role.AGGREGATOR, Role.SERVER):
             self.aggregator.set_nodes_to_aggregate(self._train_set)
@@ -302,7 +302,7 @@ class Node(BaseNode):
                 # announce first: adding the last missing model aggregates and sends MODELS_READY, and the
                 # link-order rule (NodeConnection.payload_round) needs MODELS_AGGREGATED before it
                 self.broadcast(CommunicationProtocol.build_models_aggregated_msg([self.get_name()]))
-                self.aggregator.add_model(self.learner.get_parameters(), [self.get_name()],
+                self.aggregator.add_model(self._snapshot_model(), [self.get_name()],
                                           self.learner.get_num_samples()[0])
                 if role == Role.SERVER:
                     self._gossip_model_difusion()
@@ -324,7 +324,7 @@ class Node(BaseNode):
             if self.round is not None:
                 self._local_done = True
                 self.broadcast(CommunicationProtocol.build_models_aggregated_msg([self.get_name()]))
-                self.aggregator.add_model(self.learner.get_parameters(), [self.get_name()],
+                self.aggregator.add_model(self._snapshot_model(), [self.get_name()],
                                           self.learner.get_num_samples()[0])
                 self._gossip_model_aggregation()
                 if not self._aggregation_done.is_set():
@@ -345,6 +345,13 @@ class Node(BaseNode):
             self._aggregation_done.wait(float(self._p("AGGREGATION_TIMEOUT")))
         else:
             logging.warning("[NODE] Role %s not implemented", role)
+
+    def _snapshot_model(self):
+        """Copy of the trained model for the aggregator. ``state_dict()`` hands out the live tensors and
+        ``set_parameters`` overwrites them in place, so without the copy the contribution this node keeps
+        (and forwards inside partial aggregates) would silently turn into whatever model it adopts later."""
+        return type(self.learner.get_parameters())(
+            (k, v.detach().clone()) for k, v in self.learner.get_parameters().items())
 
     def _validate_train_set(self):
         live = set(self.get_network_nodes())
@@ -399,7 +406,10 @@ class Node(BaseNode):
         self._train_set = []     # per-peer MODELS_AGGREGATED lists are reset when the peer's MODELS_READY arrives
         if self.checkpoint_dir:
             self.save_checkpoint(os.path.join(self.checkpoint_dir, f"participant_{self.idx}_round_{self.round}.ckpt"))
-        if self._p("scenario_args")["federation"] == "SDFL" and self.role == Role.AGGREGATOR:
+        # only the node that LED this round hands the role on (a node that received TRANSFER_LEADERSHIP while
+        # finishing the same round keeps it for the next one)
+        if (self._p("scenario_args")["federation"] == "SDFL" and self.role == Role.AGGREGATOR
+                and getattr(self, "_round_role", None) == Role.AGGREGATOR):
             self._transfer_aggregator_role("random")
         logging.info("[NODE] Round %s of %s finished.", self.round, self.totalrounds)
         if self.round < self.totalrounds:
@@ -487,6 +497,8 @@ class Node(BaseNode):
             if self.heartbeater is not None:
                 self.heartbeater.add_node_role(obj[0], obj[1])
         elif event == Events.AGGREGATION_FINISHED_EVENT:
+            if self._aggregation_done.is_set():
+                return          # second delivery of a round (own aggregation after an adopted diffusion): keep the first
             if obj is not None:
                 self.learner.set_parameters(obj)
                 if self.round is not None and not self._ready_sent:

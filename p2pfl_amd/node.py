@@ -437,8 +437,14 @@ class Node(BaseNode):
     # ------------------------------------------------------------------ model gossip (data plane)
     def _gossip_model_aggregation(self):
         # a peer that already announced MODELS_READY for this round needs nothing more
+        # The reference compares COUNTS (len(peer's models) < len(my train set), node.py:695). With unequal
+        # train sets (star: a trainer's is {server, self}, the server's is everyone) a trainer then believes
+        # the server is complete as soon as another trainer was faster, never sends its own model and the
+        # round only ends at AGGREGATION_TIMEOUT - so a peer that lacks OUR contribution stays a candidate.
+        me = self.get_name()
         cand = lambda nc: (nc.get_name() in self._train_set and nc.get_model_ready_status() < (self.round or 0)
-                           and len(nc.get_models_aggregated()) < len(self._train_set))
+                           and (len(nc.get_models_aggregated()) < len(self._train_set)
+                                or me not in nc.get_models_aggregated()))
         status = lambda nc: (nc.get_name(), len(nc.get_models_aggregated()))
         model = lambda nc: self.aggregator.get_partial_aggregation(nc.get_models_aggregated())
         self._gossip_model(cand, status, model)

@@ -1,0 +1,319 @@
+// Stage-1 convolution (C_in = 1; 5x5 or 7x7, "same" padding, + ReLU + 2x2 max-pool) of the MNIST / FEMNIST
+// CNNs on the gfx950 matrix cores, client-batched.
+//
+// K = 25 / 49 taps is thin for a GEMM, but with the taps laid out as k = ky*8 + kx (kx padded to 8) an
+// MFMA operand fragment (8 consecutive k) is simply 8 consecutive pixels of one image row: the padded
+// image of a sample sits in LDS as bf16 and every fragment is ONE ds_read_b128 at a pixel address
+// (gfx950 LDS reads need no alignment), no im2col, no gather.
+//
+//   forward   C_q[f][window] = sum_k W[f][k] X_q[window][k]   one wave = one image, 7 tiles of 32 pool windows, one
+//             accumulator per window position q: a lane ends up with the four pixels of ITS window for 16
+//             filters, so max / arg-max / ReLU are in-lane compares and every store instruction writes 32
+//             consecutive pooled outputs (128 B) of a filter. (A first version that put the four pixels of
+//             a window into four lanes spent 8x the VALU work on DPP exchanges and stored 32-byte pieces:
+//             0.93 ms vs 1.2 ms for the VALU kernel it replaced, 1000 FEMNIST clients.)
+//   weight    dW[f][k] = sum_{q, window} G_q[f][window] X_q[window][k]     the pooled gradient is routed to the
+//   gradient  arg-max pixel by masking with the code (4 masks of ONE operand read); the image is kept
+//             de-interleaved by column parity so that 8 consecutive windows of a window row are 8 consecutive
+//             bf16; tap 63 is an all-ones column whose product is the bias gradient. A block streams the
+//             images of a client through double-buffered LDS with coalesced loads (gradient, codes, pixels);
+//             its four waves split the 14 window rows; fp32 atomics of the per-wave [32 x 64] partials.
+//
+// Reference layers: fedstellar/learning/pytorch/mnist/models/cnn.py:134-138,151-152 (5x5),
+// fedstellar/learning/pytorch/femnist/models/cnn.py:136,147 (7x7).
+#include "common.h"
+
+namespace {
+
+constexpr int IMG = 28;
+constexpr int P1 = 14;
+constexpr int CELLS1 = 196;
+
+__device__ __forceinline__ int mfma_row(int reg, int lane) {
+    return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+}
+
+__device__ __forceinline__ bf16x8 lds_read8(const __bf16* p) {
+    bf16x8 v;
+    __builtin_memcpy(&v, p, 16);   // ds_read_b128 at a 2-byte aligned address
+    return v;
+}
+
+// A fragments of the filter bank: lane (f = lane & 31, h = lane >> 5), k-step kk covers taps ky = 2kk + h, kx = 0..7
+template <int KS, int NKK>
+__device__ __forceinline__ void load_filter_frags(const float* w, int F, bf16x8 (&wf)[NKK]) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+        const int ky = 2 * kk + h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            wf[kk][j] = (__bf16)((r < F && ky < KS && j < KS) ? w[r * KS * KS + ky * KS + j] : 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------
+struct Conv1Args {
+    const float* data; long data_cs;   // [K][n_samples][784]
+    const int* sidx;   long sidx_cs;   // [K][B] sample indices (or null: identity)
+    const float* w;    long w_cs;      // [K][F][KS*KS]
+    const float* bias; long b_cs;      // [K][F]
+    float* a1;         long a_cs;      // [K][B][F][196]
+    uint8_t* code;     long c_cs;      // [K][B][F][196]
+    int B, F;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args a) {
+    constexpr int PAD = KS / 2;
+    constexpr int NKK = (KS * 8 + 15) / 16;     // k-steps of 16 taps (two filter rows each): 3 / 4
+    constexpr int ROWS = IMG + 2 * NKK;         // last pixel row 27 + last tap row 2 NKK - 1
+    constexpr int LW = 36;                      // last pixel column 27 + kx 7 = 34
+    __shared__ __attribute__((aligned(16))) __bf16 img[4][ROWS * LW + 8];
+
+    const int c = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x * 4 + wave;
+    const bool live = b < a.B;
+    if (live) {
+        const int sample = a.sidx ? a.sidx[c * a.sidx_cs + b] : b;
+        const float* src = a.data + c * a.data_cs + (size_t)sample * (IMG * IMG);
+        for (int i = lane; i < ROWS * LW + 8; i += 64) {
+            const int y = i / LW - PAD, x = i % LW - PAD;
+            img[wave][i] = (__bf16)((y >= 0 && y < IMG && x >= 0 && x < IMG) ? src[y * IMG + x] : 0.f);
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+
+    bf16x8 wf[NKK];
+    load_filter_frags<KS, NKK>(a.w + c * a.w_cs, a.F, wf);
+    float bv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int f = mfma_row(e, lane);
+        bv[e] = f < a.F ? a.bias[c * a.b_cs + f] : 0.f;
+    }
+    float* out = a.a1 + c * a.a_cs + (size_t)b * a.F * CELLS1;
+    uint8_t* code = a.code + c * a.c_cs + (size_t)b * a.F * CELLS1;
+    for (int tile = 0; tile < (CELLS1 + 31) / 32; ++tile) {
+        const int W = tile * 32 + r;
+        const int Wc = min(W, CELLS1 - 1);
+        const int py = Wc / P1, px = Wc - py * P1;
+        f32x16 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+            const __bf16* p = img[wave] + (2 * py + (q >> 1) + h) * LW + 2 * px + (q & 1);
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk)
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk], lds_read8(p + 2 * kk * LW), acc[q], 0, 0, 0);
+        }
+        if (W < CELLS1) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float best = acc[0][e]; int qi = 0;
+                if (acc[1][e] > best) { best = acc[1][e]; qi = 1; }
+                if (acc[2][e] > best) { best = acc[2][e]; qi = 2; }
+                if (acc[3][e] > best) { best = acc[3][e]; qi = 3; }
+                best += bv[e];
+                if (!(best > 0.f)) { best = 0.f; qi = 4; }
+                const int f = mfma_row(e, lane);
+                if (f < a.F) {
+                    out[(size_t)f * CELLS1 + W] = best;
+                    code[(size_t)f * CELLS1 + W] = (uint8_t)qi;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------------
+struct Conv1WgradArgs {
+    const float* g;    long g_cs;      // da1 [K][B][F][196]
+    const uint8_t* code; long c_cs;
+    const float* data; long data_cs;
+    const int* sidx;   long sidx_cs;
+    float* dw;         long dw_cs;     // [K][F][KS*KS]  (must be zeroed)
+    float* db;         long db_cs;     // [K][F]         (must be zeroed)
+    int B, F;
+};
+
+constexpr int WG_ROWS = 36;     // last row 2*13 + 1 + tap row 7 = 34
+constexpr int WG_HW = 24;       // half-row: last index 8 + 7 + (8 >> 1) = 19
+constexpr int WG_IMG = WG_ROWS * WG_HW + 8;
+constexpr int WG_G = 32 * CELLS1 + 8;
+
+struct Conv1WgradSmem {
+    __bf16 img[2][WG_IMG];      // [parity][row][i] = padded pixel (row, 2 i + parity)
+    __bf16 g[WG_G];             // pooled gradient [f][196]
+    uint8_t code[WG_G];         // arg-max codes   [f][196]
+};
+
+// registers of one image in flight (coalesced global loads; 256 threads)
+template <int KS>
+struct Conv1WgradStage {
+    static constexpr int PAD = KS / 2;
+    static constexpr int NG = (32 * CELLS1 / 4 + 255) / 256;   // float4 of the gradient per thread: 7
+    static constexpr int NC = (32 * CELLS1 / 4 + 255) / 256;   // code words per thread: 7
+    static constexpr int NP = (2 * WG_IMG + 255) / 256;        // staged pixels per thread: 7
+    f32x4 g[NG]; uint32_t c[NC]; float px[NP];
+
+    __device__ __forceinline__ void load(const Conv1WgradArgs& a, int cl, int b) {
+        const int n4 = a.F * CELLS1 / 4;
+        const f32x4* gsrc = reinterpret_cast<const f32x4*>(a.g + cl * a.g_cs + (size_t)b * a.F * CELLS1);
+        const uint32_t* csrc = reinterpret_cast<const uint32_t*>(a.code + cl * a.c_cs + (size_t)b * a.F * CELLS1);
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int o = threadIdx.x + i * 256;
+            if (o < n4) { g[i] = gsrc[o]; c[i] = csrc[o]; }
+        }
+        const int sample = a.sidx ? a.sidx[cl * a.sidx_cs + b] : b;
+        const float* src = a.data + cl * a.data_cs + (size_t)sample * (IMG * IMG);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int o2 = threadIdx.x + i * 256;
+            const int par = o2 / WG_IMG, o = o2 - par * WG_IMG;
+            const int y = o / WG_HW - PAD, x = 2 * (o % WG_HW) + par - PAD;
+            px[i] = (o2 < 2 * WG_IMG && o < WG_ROWS * WG_HW && y >= 0 && y < IMG && x >= 0 && x < IMG) ? src[y * IMG + x] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void store(const Conv1WgradArgs& a, Conv1WgradSmem& sm) const {
+        const int n4 = a.F * CELLS1 / 4;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int o = threadIdx.x + i * 256;
+            if (o < n4) {
+                bf16x4 q;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[j] = (__bf16)g[i][j];
+                *reinterpret_cast<bf16x4*>(sm.g + 4 * o) = q;
+                *reinterpret_cast<uint32_t*>(sm.code + 4 * o) = c[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int o2 = threadIdx.x + i * 256;
+            if (o2 < 2 * WG_IMG) (&sm.img[0][0])[o2] = (__bf16)px[i];
+        }
+    }
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) Conv1WgradSmem smem[2];
+
+    const int c = blockIdx.z, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 31, h = lane >> 5;
+    // rows of filters >= F (and the read-ahead pad) stay "no gradient" for the whole kernel
+    for (int i = threadIdx.x; i < 2 * WG_G; i += 256) {
+        Conv1WgradSmem& s = smem[i / WG_G];
+        const int o = i % WG_G;
+        s.g[o] = (__bf16)0.f;
+        s.code[o] = 4;
+    }
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.f;
+
+    Conv1WgradStage<KS> st;
+    int b = blockIdx.x;
+    if (b < a.B) { st.load(a, c, b); st.store(a, smem[0]); }
+    __syncthreads();
+    int cur = 0;
+    for (; b < a.B; b += gridDim.x) {
+        const bool has_next = b + (int)gridDim.x < a.B;
+        if (has_next) st.load(a, c, b + gridDim.x);          // global loads fly while this image is consumed
+        const Conv1WgradSmem& sm = smem[cur];
+        for (int py = wave; py < P1; py += 4) {
+            // pooled gradient + codes of 8 windows (px = 8h .. 8h+7; px >= 14 is padding) of filter r
+            const int o = r * CELLS1 + py * P1 + 8 * h;
+            const bf16x8 gv = lds_read8(sm.g + o);
+            uint8_t cv[8];
+            __builtin_memcpy(cv, sm.code + o, 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bf16x8 af;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool on = cv[j] == q && (j < 6 || h == 0);
+                    af[j] = on ? gv[j] : (__bf16)0.f;
+                }
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) {
+                    // B rows: taps n = jn*32 + r = ky*8 + kx; pixel of window px: (2py + dy + ky, 2px + dx + kx)
+                    const int n = jn * 32 + r, ky = n >> 3, kx = n & 7;
+                    const int v = (q & 1) + kx;
+                    const __bf16* p = sm.img[v & 1] + (2 * py + (q >> 1) + ky) * WG_HW + 8 * h + (v >> 1);
+                    const bf16x8 bfr = (n == 63) ? ones : lds_read8(p);
+                    acc[jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[jn], 0, 0, 0);
+                }
+            }
+        }
+        if (has_next) st.store(a, smem[cur ^ 1]);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // acc[jn][e] = partial dW[f = mfma_row(e)][tap n = jn*32 + r] of this wave's window rows
+    float* dw = a.dw + c * a.dw_cs;
+    float* db = a.db + c * a.db_cs;
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+        const int n = jn * 32 + r, ky = n >> 3, kx = n & 7;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int fo = mfma_row(e, lane);
+            if (fo >= a.F) continue;
+            if (n == 63) atomicAdd(db + fo, acc[jn][e]);
+            else if (ky < KS && kx < KS) atomicAdd(dw + fo * KS * KS + ky * KS + kx, acc[jn][e]);
+        }
+    }
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+P2PFL_API int p2pfl_conv1_fwd(const float* data, long data_cs, const int* sidx, long sidx_cs,
+                              const float* w, long w_cs, const float* bias, long b_cs, float* a1,
+                              long a_cs, uint8_t* code, long c_cs, int K, int B, int F, int KS,
+                              hipStream_t stream) {
+    if (K <= 0 || B <= 0 || F <= 0 || F > 32) return -1;
+    Conv1Args a{data, data_cs, sidx, sidx_cs, w, w_cs, bias, b_cs, a1, a_cs, code, c_cs, B, F};
+    dim3 grid(cdiv(B, 4), K);
+    if (KS == 5) hipLaunchKernelGGL(conv1_fwd_kernel<5>, grid, dim3(256), 0, stream, a);
+    else if (KS == 7) hipLaunchKernelGGL(conv1_fwd_kernel<7>, grid, dim3(256), 0, stream, a);
+    else return -3;
+    P2PFL_RETURN_LAST_ERROR();
+}
+
+P2PFL_API int p2pfl_conv1_wgrad(const float* g, long g_cs, const uint8_t* code, long c_cs,
+                                const float* data, long data_cs, const int* sidx, long sidx_cs,
+                                float* dw, long dw_cs, float* db, long db_cs, int K, int B, int F,
+                                int KS, hipStream_t stream) {
+    if (K <= 0 || B <= 0 || F <= 0 || F > 32) return -1;
+    // dw/db are accumulated with atomics: the caller zeroes them first (p2pfl_zero_rows).
+    // float4 / word loads of the pooled gradient and the codes of an image
+    if (((uintptr_t)g & 15) || (g_cs & 3) || ((uintptr_t)code & 3) || (c_cs & 3)) return -2;
+    // blocks per client: enough to put ~3 blocks on every CU, at most one per image
+    int splits = cdiv(768, K);
+    if (splits > B) splits = B;
+    if (splits < 1) splits = 1;
+    Conv1WgradArgs a{g, g_cs, code, c_cs, data, data_cs, sidx, sidx_cs, dw, dw_cs, db, db_cs, B, F};
+    dim3 grid(splits, 1, K);
+    if (KS == 5) hipLaunchKernelGGL(conv1_wgrad_kernel<5>, grid, dim3(256), 0, stream, a);
+    else if (KS == 7) hipLaunchKernelGGL(conv1_wgrad_kernel<7>, grid, dim3(256), 0, stream, a);
+    else return -3;
+    P2PFL_RETURN_LAST_ERROR();
+}

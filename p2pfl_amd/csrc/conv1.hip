@@ -78,11 +78,25 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args a) {
     const int b = blockIdx.x * 4 + wave;
     const bool live = b < a.B;
     if (live) {
+        // 196 float4 of the image in flight at once, the zero border meanwhile, then 4 pixels per LDS write
         const int sample = a.sidx ? a.sidx[c * a.sidx_cs + b] : b;
-        const float* src = a.data + c * a.data_cs + (size_t)sample * (IMG * IMG);
-        for (int i = lane; i < ROWS * LW + 8; i += 64) {
-            const int y = i / LW - PAD, x = i % LW - PAD;
-            img[wave][i] = (__bf16)((y >= 0 && y < IMG && x >= 0 && x < IMG) ? src[y * IMG + x] : 0.f);
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.data + c * a.data_cs + (size_t)sample * (IMG * IMG));
+        f32x4 px[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (lane + 64 * i < IMG * IMG / 4) px[i] = src[lane + 64 * i];
+        for (int i = lane; i < (ROWS * LW + 8) / 2; i += 64) reinterpret_cast<uint32_t*>(img[wave])[i] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // zero fill before the pixels (same wave, same words)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = lane + 64 * i;
+            if (o < IMG * IMG / 4) {
+                const int y = o / (IMG / 4), x = 4 * (o - y * (IMG / 4));
+                bf16x4 q;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[j] = (__bf16)px[i][j];
+                __builtin_memcpy(img[wave] + (y + PAD) * LW + x + PAD, &q, 8);
+            }
         }
     }
     __syncthreads();
@@ -290,6 +304,7 @@ P2PFL_API int p2pfl_conv1_fwd(const float* data, long data_cs, const int* sidx, 
                               long a_cs, uint8_t* code, long c_cs, int K, int B, int F, int KS,
                               hipStream_t stream) {
     if (K <= 0 || B <= 0 || F <= 0 || F > 32) return -1;
+    if (((uintptr_t)data & 15) || (data_cs & 3)) return -2;      // float4 loads of whole 784-pixel images
     Conv1Args a{data, data_cs, sidx, sidx_cs, w, w_cs, bias, b_cs, a1, a_cs, code, c_cs, B, F};
     dim3 grid(cdiv(B, 4), K);
     if (KS == 5) hipLaunchKernelGGL(conv1_fwd_kernel<5>, grid, dim3(256), 0, stream, a);

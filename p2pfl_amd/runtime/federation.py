@@ -41,6 +41,7 @@ from ..parallel.planner import link_key, partition_nodes, plan_exchange  # noqa:
 from ..role import Role, default_roles
 from .aggregation import AggregationPlan, build_plan, plan_from_train_sets, run_plan
 from .engine import ShardEngine, make_engine
+from .membership import VirtualMembership
 
 
 @dataclass
@@ -60,7 +61,8 @@ class BatchedFederation:
                  device="cpu", engine: str = "auto", batch_size: int = 32, epochs: int = 1, seed: int = 0,
                  rank: int = 0, world_size: int = 1, process_group=None, encrypt: bool = False,
                  scenario: str = "scenario", persist_optimizer: bool = False, use_graph: bool = True,
-                 overlap: bool = True):
+                 overlap: bool = True, heartbeat_period: float = 4.0, node_timeout: float = 20.0,
+                 instant_detection: bool = True):
         self.spec = spec
         self.adj = np.asarray(topology, dtype=np.float32)
         self.N = self.adj.shape[0]
@@ -81,6 +83,8 @@ class BatchedFederation:
         self.engine: ShardEngine = make_engine(spec, self.n_local, self.device, impl=engine, batch_size=batch_size,
                                                seed=seed, persist_optimizer=persist_optimizer,
                                                **({"use_graph": use_graph, "overlap": overlap} if engine != "eager" else {}))
+        # membership of ALL nodes of the scenario (every rank applies the same deterministic schedule)
+        self.membership = VirtualMembership(self.N, heartbeat_period, node_timeout, instant=instant_detection)
         self.alive = np.ones(self.N, dtype=bool)
         self.weights = np.zeros(self.N, dtype=np.float64)       # training samples per node
         self.round = 0
@@ -88,7 +92,7 @@ class BatchedFederation:
         self.comm = DeviceExchange(rank, world_size, process_group, self.device, encrypt, scenario)
         self.staging: Optional[torch.Tensor] = None
         self._plan_cache: Dict[bytes, tuple] = {}
-        self.faults: Dict[int, List[tuple]] = {}                  # round -> [(action, node)]
+        self.trace = bool(int(__import__("os").environ.get("P2PFL_TRACE", "0")))   # roctx ranges around the phases
         self.reports: List[RoundReport] = []
 
     # ------------------------------------------------------------------ setup
@@ -105,13 +109,14 @@ class BatchedFederation:
         else:
             self.weights[:] = np.asarray(n_train_all, dtype=np.float64)
 
-    def schedule_fault(self, round_idx: int, action: str, node: int) -> None:
-        """Deterministic churn: ``action`` in {"kill", "revive"} applied at the start of a round."""
-        self.faults.setdefault(round_idx, []).append((action, node))
+    def schedule_fault(self, round_idx: int, action: str, node: int, peer: Optional[int] = None) -> None:
+        """Deterministic churn applied at the start of a round: ``kill`` / ``revive`` / ``pause`` / ``resume``
+        of a node, ``drop_link`` / ``restore_link`` of the edge (node, peer); see runtime/membership.py."""
+        self.membership.schedule(round_idx, action, node, peer)
 
     # ------------------------------------------------------------------ per-round structure
     def neighbors(self, i: int) -> List[int]:
-        return [int(j) for j in np.nonzero(self.adj[i])[0] if j != i]
+        return [int(j) for j in np.nonzero(self.adj[i])[0] if j != i and self.membership.link_up(i, int(j))]
 
     def train_set(self, i: int) -> List[int]:
         if not self.alive[i]:
@@ -138,6 +143,7 @@ class BatchedFederation:
     def _structure_key(self) -> bytes:
         h = hashlib.sha1()
         h.update(self.alive.tobytes())
+        h.update(repr(sorted(self.membership.dropped)).encode())
         h.update("|".join(self.roles).encode())
         return h.digest()
 
@@ -161,8 +167,15 @@ class BatchedFederation:
 
     # ------------------------------------------------------------------ the round
     def _apply_faults(self) -> None:
-        for action, node in self.faults.get(self.round, []):
-            self.alive[node] = action != "kill"
+        self.membership.apply_round(self.round)
+        self.alive = self.membership.alive().copy()
+
+    def _range(self, name: str):
+        """roctx range (visible in rocprofv3 --marker-trace) when P2PFL_TRACE=1."""
+        if self.trace and self.device.type == "cuda":
+            torch.cuda.nvtx.range_push(name)
+            return True
+        return False
 
     def aggregate(self) -> int:
         """Exchange + FedAvg for the current membership/roles. Returns #rows received from peers."""
@@ -232,16 +245,28 @@ class BatchedFederation:
         t = t0
         test = None
         if evaluate:                      # evaluation happens BEFORE training (node.py:433-435)
+            pushed = self._range("evaluate")
             test = eng.evaluate()
+            if pushed:
+                torch.cuda.nvtx.range_pop()
             t = tick("evaluate", t)
         lo = self.local.start
         active = torch.tensor([bool(self.alive[i]) and Role.trains(self.roles[i]) for i in self.local])
+        pushed = self._range("train")
         fit = eng.fit(self.epochs, active=active)
+        if pushed:
+            torch.cuda.nvtx.range_pop()
         t = tick("train", t)
+        pushed = self._range("exchange+aggregate")
         got = self.aggregate()
+        if pushed:
+            torch.cuda.nvtx.range_pop()
         t = tick("aggregate", t)
         if self.federation == "SDFL":
             self._transfer_leadership()
+        # virtual heartbeats: the clock moves by the wall time of the round (at least one period)
+        self.membership.advance(max(time.perf_counter() - t0, self.membership.period))
+        self.alive = self.membership.alive().copy()
         n_train = eng.train_x.shape[1]
         rep = RoundReport(self.round, time.perf_counter() - t0, phases,
                           int(active.sum().item()) * n_train * self.epochs,

@@ -61,8 +61,20 @@ def adjacency_from_participants(parts: List[dict]) -> np.ndarray:
     return adj
 
 
+def load_faults(config_dir: str, parts: List[dict]) -> List[dict]:
+    """Fault schedule of a scenario: ``faults.json`` in the config directory and/or ``scenario_args.faults`` of
+    participant 0 - a list of ``{"round": r, "action": "kill|revive|pause|resume|drop_link|restore_link",
+    "node": i[, "peer": j]}``."""
+    out = list(parts[0]["scenario_args"].get("faults") or [])
+    path = os.path.join(config_dir, "faults.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            out += json.load(f)
+    return out
+
+
 def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, save_models: bool = False,
-                 rounds: int = None) -> dict:
+                 rounds: int = None, resume: str = None) -> dict:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -92,12 +104,24 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
 
     fed = BatchedFederation(spec, adjacency_from_participants(parts), federation=federation, roles=roles, device=dev,
                             epochs=epochs, seed=int(p0["scenario_args"].get("random_seed", 0)), rank=rank,
-                            world_size=world, process_group=pg, encrypt=encrypt, scenario=scenario)
+                            world_size=world, process_group=pg, encrypt=encrypt, scenario=scenario,
+                            heartbeat_period=float(p0.get("HEARTBEAT_PERIOD", 4)),
+                            node_timeout=float(p0.get("NODE_TIMEOUT", 20)))
+    for f in load_faults(config_dir, parts):
+        fed.schedule_fault(int(f["round"]), f["action"], int(f["node"]), f.get("peer"))
     # data shards of the local nodes (real files when present, synthetic otherwise)
     shards = [build_dataset_and_model(key[0], key[1], i, n, p0["data_args"].get("root_dir"))[0] for i in fed.local]
     stack = lambda idx: None if shards[0].tensors()[idx] is None else torch.stack([s.tensors()[idx] for s in shards])
     fed.init_params()
     fed.set_local_data(*(stack(i) for i in range(6)))
+    first_round = 0
+    if resume:
+        # resume = every node restarts from its checkpoint (the reference payload bytes)
+        from ..learning.codec import load_checkpoint
+        for k, i in enumerate(fed.local):
+            arrays, _, _, meta = load_checkpoint(os.path.join(resume, f"participant_{i}_final.ckpt"))
+            fed.engine.layout.arrays_to_row(arrays, fed.engine.params[k])
+            first_round = max(first_round, int((meta or {}).get("round", 0)))
 
     log_root = os.path.join(p0["tracking_args"].get("log_dir") or "logs", scenario)
     os.makedirs(log_root, exist_ok=True)
@@ -123,13 +147,16 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
 
     t0 = time.time()
     total_samples = 0
-    for r in range(rounds):
+    for r in range(first_round, first_round + rounds):
         rep = fed.run_round()
         total_samples += rep.train_samples
         test = fed.engine.stats["Test"].summary()
         train = fed.engine.stats["Train"].summary()
         for k, i in enumerate(fed.local):
-            m = {"Round": r, "Test/Loss": float(test["loss"][k]), "Train/Loss": float(train["loss"][k])}
+            m = {"Round": r, "Test/Loss": float(test["loss"][k]), "Train/Loss": float(train["loss"][k]),
+                 "Federation/RoundSeconds": rep.seconds, "Federation/ExchangedRows": rep.exchanged_rows}
+            for ph, sec in rep.phase_seconds.items():
+                m[f"Federation/Phase_{ph}_seconds"] = sec
             for ph, st in (("Test", test), ("Train", train)):
                 for name, v in metrics_from_confusion(st["confusion"][k]).items():
                     if name != "MicroAccuracy":
@@ -146,7 +173,7 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
             save_checkpoint(os.path.join(log_root, f"participant_{i}_final.ckpt"),
                             fed.engine.layout.row_to_arrays(fed.engine.params[k]),
                             [f"{parts[i]['network_args']['ip']}:{parts[i]['network_args']['port']}"],
-                            int(fed.weights[i]), meta={"round": rounds, "role": fed.roles[i]})
+                            int(fed.weights[i]), meta={"round": first_round + rounds, "role": fed.roles[i]})
     for f in node_logs.values():
         f.close()
     for lg in loggers.values():
@@ -154,7 +181,8 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
     summary = {"scenario": scenario, "rank": rank, "world": world, "nodes": n, "local_nodes": fed.n_local,
                "rounds": rounds, "seconds": elapsed, "rounds_per_sec": rounds / elapsed,
                "samples_per_sec": total_samples / elapsed, "final_test_accuracy": float(final["accuracy"].mean()),
-               "final_test_loss": float(final["loss"].mean())}
+               "final_test_loss": float(final["loss"].mean()), "first_round": first_round,
+               "membership_events": [[round(t, 3), what, node] for t, what, node in fed.membership.events]}
     if rank == 0:
         with open(os.path.join(log_root, "summary.json"), "w") as f:
             json.dump(summary, f, indent=2)
@@ -170,9 +198,10 @@ def main(argv=None):
     ap.add_argument("--encrypt", action="store_true")
     ap.add_argument("--save-models", action="store_true")
     ap.add_argument("--rounds", type=int, default=None)
+    ap.add_argument("--resume", default=None, help="directory with participant_<i>_final.ckpt files to start from")
     a = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO)
-    print(json.dumps(run_scenario(a.config_dir, a.device, a.encrypt, a.save_models, a.rounds)), flush=True)
+    print(json.dumps(run_scenario(a.config_dir, a.device, a.encrypt, a.save_models, a.rounds, a.resume)), flush=True)
 
 
 if __name__ == "__main__":

@@ -81,6 +81,37 @@ def test_batched_launcher_runs_scenario(tmp_path):
     assert os.path.exists(os.path.join(a.logs, "scen", "metrics", "participant_3", "metrics.csv"))
 
 
+def test_batched_launcher_faults_checkpoints_and_resume(tmp_path):
+    """faults.json drives the virtual membership; --save-models writes reference-format checkpoints; a second
+    run resumes every node from them and continues the round numbering."""
+    from p2pfl_amd.runtime.launch import run_scenario
+    cdir = os.path.join(str(tmp_path), "config", "scen")
+    Controller.generate_participants(cdir, 4, "DFL", "MNIST", "MLP", rounds=2, epochs=1, accelerator="cpu",
+                                     controller="", overrides={"tracking_args": {"log_dir": str(tmp_path / "logs")}})
+    # neighbours (ring) written by hand: the controller normally does it in load_configurations_and_start_nodes
+    for i in range(4):
+        path = os.path.join(cdir, f"participant_{i}.json")
+        p = json.load(open(path))
+        p["network_args"]["neighbors"] = " ".join(f"127.0.0.1:{45000 + j}" for j in ((i - 1) % 4, (i + 1) % 4))
+        p["scenario_args"]["name"] = "scen"
+        json.dump(p, open(path, "w"))
+    json.dump([{"round": 1, "action": "kill", "node": 3}], open(os.path.join(cdir, "faults.json"), "w"))
+    s1 = run_scenario(cdir, device="cpu", save_models=True)
+    assert s1["rounds"] == 2 and s1["first_round"] == 0 and [e[1:] for e in s1["membership_events"]] == [["kill", 3]]
+    log3 = open(tmp_path / "logs" / "scen" / "participant_3.log").read()
+    assert "round 0 role aggregator alive True" in log3 and "round 1 role aggregator alive False" in log3
+    rows = open(tmp_path / "logs" / "scen" / "metrics" / "participant_0" / "metrics.csv").read()
+    assert "Federation/RoundSeconds" in rows and "Federation/Phase_train_seconds" in rows
+    ck = tmp_path / "logs" / "scen" / "participant_0_final.ckpt"
+    assert ck.exists() and json.load(open(str(ck) + ".json"))["round"] == 2
+    os.remove(os.path.join(cdir, "faults.json"))
+    s2 = run_scenario(cdir, device="cpu", rounds=1, resume=str(tmp_path / "logs" / "scen"))
+    assert s2["first_round"] == 2 and s2["rounds"] == 1
+    # resumed from trained weights: the very first evaluation is already good
+    first_eval = [l for l in open(tmp_path / "logs" / "scen" / "participant_1.log").read().splitlines() if "round 2 " in l][0]
+    assert float(first_eval.split("test_acc ")[1].split()[0]) > 0.5
+
+
 @pytest.mark.slow
 def test_config1_two_processes_tcp_mnist_mlp(tmp_path, monkeypatch):
     monkeypatch.setenv("P2PFL_START_DELAY", "1")

@@ -130,6 +130,48 @@ def test_killed_node_is_dropped_from_train_sets_and_keeps_its_model():
     assert fed.alive.all()
 
 
+def test_virtual_membership_clock_eviction_and_links():
+    """Heartbeat semantics on the virtual clock (reference heartbeater.py:66-111: beat every HEARTBEAT_PERIOD,
+    evict after NODE_TIMEOUT), without instant detection."""
+    from p2pfl_amd.runtime.membership import VirtualMembership
+    m = VirtualMembership(4, heartbeat_period=4.0, node_timeout=20.0, instant=False)
+    m.schedule(1, "kill", 2)
+    m.schedule(1, "drop_link", 0, 1)
+    m.schedule(3, "revive", 2)
+    m.schedule(3, "restore_link", 1, 0)
+    assert m.apply_round(0) == [] and m.advance(8.0) == [] and m.get_nodes() == [0, 1, 2, 3]
+    m.apply_round(1)
+    assert not m.alive()[2] and m.get_nodes() == [0, 1, 2, 3]          # silent, but not evicted yet
+    assert not m.link_up(1, 0) and m.link_up(0, 2)
+    assert m.advance(16.0) == []                                         # 16 s of silence < NODE_TIMEOUT
+    assert m.advance(8.0) == [2] and m.get_nodes() == [0, 1, 3]          # 24 s > 20 s: evicted
+    m.apply_round(3)
+    assert m.alive().all() and m.get_nodes() == [0, 1, 2, 3] and m.link_up(0, 1)
+    assert [e[1] for e in m.events] == ["kill", "evicted", "revive"]
+    with pytest.raises(ValueError):
+        m.schedule(0, "explode", 1)
+    with pytest.raises(ValueError):
+        m.schedule(0, "drop_link", 1)
+
+
+def test_dropped_link_and_paused_node_change_the_train_sets():
+    fed = make_fed("ring", 5)
+    perturb(fed)
+    base = fed.engine.params[0, 0].item()
+    fed.schedule_fault(0, "drop_link", 1, 2)       # ring 0-1-2-3-4-0 loses the edge 1-2
+    fed.schedule_fault(0, "pause", 4)
+    fed.run_round(evaluate=False)
+    assert fed.train_set(1) == [0, 1] and fed.train_set(2) == [2, 3] and fed.train_set(0) == [0, 1]
+    assert abs(fed.engine.params[1, 0].item() - (base + (0.01 + 0.02) / 2)) < 1e-6      # nodes 0, 1
+    assert abs(fed.engine.params[2, 0].item() - (base + (0.03 + 0.04) / 2)) < 1e-6      # nodes 2, 3
+    assert abs(fed.engine.params[4, 0].item() - base) < 1e-7                            # paused: untouched
+    fed.schedule_fault(1, "resume", 4)
+    fed.schedule_fault(1, "restore_link", 2, 1)
+    fed.run_round(evaluate=False)
+    assert fed.alive.all() and fed.train_set(1) == [0, 1, 2]
+    assert [e[1] for e in fed.membership.events] == ["pause", "resume"]
+
+
 # ------------------------------------------------------------------ 2 ranks over gloo
 def _free_port():
     s = socket.socket()

@@ -62,7 +62,7 @@ struct Conv1Args {
     const float* bias; long b_cs;      // [K][F]
     float* a1;         long a_cs;      // [K][B][F][196]
     uint8_t* code;     long c_cs;      // [K][B][F][196]
-    int B, F;
+    int B, F, ipw;
 };
 
 template <int KS>
@@ -71,37 +71,29 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args a) {
     constexpr int NKK = (KS * 8 + 15) / 16;     // k-steps of 16 taps (two filter rows each): 3 / 4
     constexpr int ROWS = IMG + 2 * NKK;         // last pixel row 27 + last tap row 2 NKK - 1
     constexpr int LW = 36;                      // last pixel column 27 + kx 7 = 34
+    constexpr int NPX = IMG * IMG / 4;          // float4 per image
+    // one private image per wave: no workgroup barrier anywhere in this kernel
     __shared__ __attribute__((aligned(16))) __bf16 img[4][ROWS * LW + 8];
 
     const int c = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.x * 4 + wave;
-    const bool live = b < a.B;
-    if (live) {
-        // 196 float4 of the image in flight at once, the zero border meanwhile, then 4 pixels per LDS write
-        const int sample = a.sidx ? a.sidx[c * a.sidx_cs + b] : b;
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.data + c * a.data_cs + (size_t)sample * (IMG * IMG));
-        f32x4 px[4];
+    __bf16* my = img[wave];
+    const int ipw = a.ipw;                                   // images per wave (weights / bias loaded once)
+    int b = (blockIdx.x * ipw) * 4 + wave;
+    if (b >= a.B) return;
+    const float* data = a.data + c * a.data_cs;
+    const int* sidx = a.sidx ? a.sidx + c * a.sidx_cs : nullptr;
+    auto image = [&](int bi) {
+        return reinterpret_cast<const f32x4*>(data + (size_t)(sidx ? sidx[bi] : bi) * (IMG * IMG));
+    };
+    f32x4 px[4];
+    {
+        const f32x4* src = image(b);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (lane + 64 * i < IMG * IMG / 4) px[i] = src[lane + 64 * i];
-        for (int i = lane; i < (ROWS * LW + 8) / 2; i += 64) reinterpret_cast<uint32_t*>(img[wave])[i] = 0u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // zero fill before the pixels (same wave, same words)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int o = lane + 64 * i;
-            if (o < IMG * IMG / 4) {
-                const int y = o / (IMG / 4), x = 4 * (o - y * (IMG / 4));
-                bf16x4 q;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) q[j] = (__bf16)px[i][j];
-                __builtin_memcpy(img[wave] + (y + PAD) * LW + x + PAD, &q, 8);
-            }
-        }
+            if (lane + 64 * i < NPX) px[i] = src[lane + 64 * i];
     }
-    __syncthreads();
-    if (!live) return;
-
+    for (int i = lane; i < (ROWS * LW + 8) / 2; i += 64) reinterpret_cast<uint32_t*>(my)[i] = 0u;   // zero border, once
     bf16x8 wf[NKK];
     load_filter_frags<KS, NKK>(a.w + c * a.w_cs, a.F, wf);
     float bv[16];
@@ -110,35 +102,63 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args a) {
         const int f = mfma_row(e, lane);
         bv[e] = f < a.F ? a.bias[c * a.b_cs + f] : 0.f;
     }
-    float* out = a.a1 + c * a.a_cs + (size_t)b * a.F * CELLS1;
-    uint8_t* code = a.code + c * a.c_cs + (size_t)b * a.F * CELLS1;
-    for (int tile = 0; tile < (CELLS1 + 31) / 32; ++tile) {
-        const int W = tile * 32 + r;
-        const int Wc = min(W, CELLS1 - 1);
-        const int py = Wc / P1, px = Wc - py * P1;
-        f32x16 acc[4];
+    for (int it = 0; it < ipw && b < a.B; ++it, b += 4) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // previous image consumed / border zeroed
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int i = 0; i < 4; ++i) {
+            const int o = lane + 64 * i;
+            if (o < NPX) {
+                const int y = o / (IMG / 4), x = 4 * (o - y * (IMG / 4));
+                bf16x4 q;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
-            const __bf16* p = img[wave] + (2 * py + (q >> 1) + h) * LW + 2 * px + (q & 1);
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk)
-                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk], lds_read8(p + 2 * kk * LW), acc[q], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) q[j] = (__bf16)px[i][j];
+                __builtin_memcpy(my + (y + PAD) * LW + x + PAD, &q, 8);
+            }
         }
-        if (W < CELLS1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (it + 1 < ipw && b + 4 < a.B) {                       // next image in flight during the MFMAs
+            const f32x4* src = image(b + 4);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float best = acc[0][e]; int qi = 0;
-                if (acc[1][e] > best) { best = acc[1][e]; qi = 1; }
-                if (acc[2][e] > best) { best = acc[2][e]; qi = 2; }
-                if (acc[3][e] > best) { best = acc[3][e]; qi = 3; }
-                best += bv[e];
-                if (!(best > 0.f)) { best = 0.f; qi = 4; }
-                const int f = mfma_row(e, lane);
-                if (f < a.F) {
-                    out[(size_t)f * CELLS1 + W] = best;
-                    code[(size_t)f * CELLS1 + W] = (uint8_t)qi;
+            for (int i = 0; i < 4; ++i)
+                if (lane + 64 * i < NPX) px[i] = src[lane + 64 * i];
+        }
+        float* out = a.a1 + c * a.a_cs + (size_t)b * a.F * CELLS1;
+        uint8_t* code = a.code + c * a.c_cs + (size_t)b * a.F * CELLS1;
+        for (int tile = 0; tile < (CELLS1 + 31) / 32; ++tile) {
+            const int W = tile * 32 + r;
+            const int Wc = min(W, CELLS1 - 1);
+            const int py = Wc / P1, pxx = Wc - py * P1;
+            float best[16]; int qi[16];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {               // window rows dy = 0, 1: two accumulators each
+                f32x16 acc[2];
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
+                const __bf16* p = my + (2 * py + half + h) * LW + 2 * pxx;
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d)
+                        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk], lds_read8(p + d + 2 * kk * LW), acc[d], 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (half == 0) { best[e] = acc[0][e]; qi[e] = 0; }
+                    else if (acc[0][e] > best[e]) { best[e] = acc[0][e]; qi[e] = 2; }
+                    if (acc[1][e] > best[e]) { best[e] = acc[1][e]; qi[e] = 2 * half + 1; }
+                }
+            }
+            if (W < CELLS1) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = best[e] + bv[e]; int q = qi[e];
+                    if (!(v > 0.f)) { v = 0.f; q = 4; }
+                    const int f = mfma_row(e, lane);
+                    if (f < a.F) {
+                        out[(size_t)f * CELLS1 + W] = v;
+                        code[(size_t)f * CELLS1 + W] = (uint8_t)q;
+                    }
                 }
             }
         }
@@ -305,8 +325,12 @@ P2PFL_API int p2pfl_conv1_fwd(const float* data, long data_cs, const int* sidx, 
                               hipStream_t stream) {
     if (K <= 0 || B <= 0 || F <= 0 || F > 32) return -1;
     if (((uintptr_t)data & 15) || (data_cs & 3)) return -2;      // float4 loads of whole 784-pixel images
-    Conv1Args a{data, data_cs, sidx, sidx_cs, w, w_cs, bias, b_cs, a1, a_cs, code, c_cs, B, F};
-    dim3 grid(cdiv(B, 4), K);
+    // images per wave: amortise the filter / bias loads once there are >= ~2 waves per SIMD anyway
+    int ipw = (int)(((long)K * B / 4) / 2048);
+    if (ipw < 1) ipw = 1;
+    if (ipw > 8) ipw = 8;
+    Conv1Args a{data, data_cs, sidx, sidx_cs, w, w_cs, bias, b_cs, a1, a_cs, code, c_cs, B, F, ipw};
+    dim3 grid(cdiv(B, 4 * ipw), K);
     if (KS == 5) hipLaunchKernelGGL(conv1_fwd_kernel<5>, grid, dim3(256), 0, stream, a);
     else if (KS == 7) hipLaunchKernelGGL(conv1_fwd_kernel<7>, grid, dim3(256), 0, stream, a);
     else return -3;

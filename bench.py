@@ -101,7 +101,7 @@ def main() -> None:
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
     pg = None
-    if world > 1:
+    if world > 1 or os.environ.get("P2PFL_FORCE_PG"):      # P2PFL_FORCE_PG: 1-rank RCCL communicator (smoke test of the multi-rank path)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if args.cpu else "nccl", rank=rank, world_size=world,
                                 **({} if args.cpu else {"device_id": device}))
@@ -122,7 +122,7 @@ def main() -> None:
     fed.set_local_data(tx, ty, vx, vy, ex, ey)
 
     def sync():
-        if world > 1:
+        if pg is not None:
             dist.barrier()
         if device.type == "cuda":
             torch.cuda.synchronize()
@@ -146,7 +146,7 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
 
     stats = torch.tensor([elapsed, float(samples)], dtype=torch.float64, device=device)
-    if world > 1:
+    if pg is not None:
         tmax = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         ssum = stats[1:].clone()
@@ -183,7 +183,7 @@ def main() -> None:
             },
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if pg is not None:
         dist.destroy_process_group()
 
 

@@ -70,15 +70,18 @@ class DeviceExchange:
         if self._backend() == "nccl":
             dist.all_to_all(outs, ins, group=self.pg)
             return
-        ops = []
+        ops, staged = [], {}
         for r in range(self.world):
             if r == self.rank:
                 outs[r].copy_(ins[r])
                 continue
-            ops.append(dist.P2POp(dist.irecv, outs[r], r, group=self.pg))
-            ops.append(dist.P2POp(dist.isend, ins[r].contiguous(), r, group=self.pg))
+            staged[r] = torch.empty(outs[r].shape, dtype=outs[r].dtype)
+            ops.append(dist.P2POp(dist.irecv, staged[r], r, group=self.pg))
+            ops.append(dist.P2POp(dist.isend, ins[r].contiguous().cpu(), r, group=self.pg))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        for r, t in staged.items():
+            outs[r].copy_(t)
 
     def exchange_rows(self, params: torch.Tensor, send_rows: Sequence[Sequence[int]],
                       recv_counts: Sequence[int], staging: torch.Tensor) -> int:
@@ -107,18 +110,22 @@ class DeviceExchange:
             dist.all_to_all_single(recv_cat, send_cat, output_split_sizes=list(recv_counts),
                                    input_split_sizes=send_counts, group=self.pg)
         else:
-            recv_cat = torch.empty(n_recv, P, device=self.device)
+            # gloo: point-to-point on host memory (device tensors are staged through the CPU, which also lets
+            # several ranks share ONE GPU in tests - RCCL refuses two ranks on a device)
+            host_send = send_cat.cpu()
+            host_recv = torch.empty(n_recv, P)
             ops, off, soff = [], 0, 0
             for r in range(self.world):
                 if recv_counts[r]:
-                    ops.append(dist.P2POp(dist.irecv, recv_cat[off:off + recv_counts[r]], r, group=self.pg))
+                    ops.append(dist.P2POp(dist.irecv, host_recv[off:off + recv_counts[r]], r, group=self.pg))
                     off += recv_counts[r]
                 if send_counts[r]:
-                    ops.append(dist.P2POp(dist.isend, send_cat[soff:soff + send_counts[r]], r, group=self.pg))
+                    ops.append(dist.P2POp(dist.isend, host_send[soff:soff + send_counts[r]], r, group=self.pg))
                     soff += send_counts[r]
             if ops:
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
+            recv_cat = host_recv.to(self.device)
         if self.encrypt:
             off = 0
             for r in range(self.world):
@@ -135,7 +142,12 @@ class DeviceExchange:
             return partial
         self.bytes_sent += partial.numel() * 4
         if not self.encrypt:
-            dist.all_reduce(partial, group=self.pg)
+            if self._backend() != "nccl" and partial.is_cuda:
+                host = partial.cpu()
+                dist.all_reduce(host, group=self.pg)
+                partial.copy_(host)
+            else:
+                dist.all_reduce(partial, group=self.pg)
             return partial
         enc = [self.crypt(partial, r, False) if r != self.rank else partial for r in range(self.world)]
         outs = [torch.empty_like(partial) for _ in range(self.world)]

@@ -57,7 +57,7 @@ class ShardEngine:
     """Common state + contract of the two engines."""
 
     def __init__(self, spec: ModelSpec, n_clients: int, device="cpu", batch_size: int = 32, seed: int = 0,
-                 persist_optimizer: bool = False):
+                 persist_optimizer: bool = False, client_offset: int = 0):
         self.spec = spec
         self.K = int(n_clients)
         self.device = torch.device(device)
@@ -68,8 +68,8 @@ class ShardEngine:
         self.params = self.layout.alloc(self.K, self.device)
         self.params_alt = None                        # aggregation output (allocated on first use)
         self.stats = {ph: PhaseStats.alloc(self.K, spec.num_classes, self.device) for ph in PHASES}
-        self.gen = torch.Generator(device="cpu")
-        self.gen.manual_seed(seed)
+        self.client_offset = int(client_offset)       # global id of client 0 (this rank's first node)
+        self._perm_calls = 0
         self.train_x = self.train_y = self.val_x = self.val_y = self.test_x = self.test_y = None
         self.opt_steps = 0
 
@@ -130,11 +130,26 @@ class ShardEngine:
         return math.ceil(self.train_x.shape[1] / self.B)
 
     def _epoch_perms(self, epochs: int) -> torch.Tensor:
-        """[epochs, K, steps*B] int32 shuffles (padded with wrapped indices; padded rows are masked)."""
+        """[epochs, K, steps*B] int32 shuffles (padded with wrapped indices; padded rows are masked).
+
+        The shuffle of a client is a pure function of (seed, GLOBAL client id, fit call, epoch): a
+        counter-based hash instead of a stateful generator, so a federation gives the same result however
+        its nodes are split over ranks."""
         n = self.train_x.shape[1]
         steps = self.steps_per_epoch()
-        r = torch.rand(epochs, self.K, n, generator=self.gen)
-        perm = r.argsort(dim=2).to(torch.int32)
+        i64 = torch.int64
+        e = torch.arange(epochs, dtype=i64).view(-1, 1, 1)
+        k = (torch.arange(self.K, dtype=i64) + self.client_offset).view(1, -1, 1)
+        i = torch.arange(n, dtype=i64).view(1, 1, -1)
+        x = i * -7046029254386353131                                                      # 0x9E3779B97F4A7C15 as int64
+        c = (self._perm_calls * 1442695040888963407 + int(self.seed) * 3935559000370003845) & 0xFFFFFFFFFFFFFFFF
+        c = c - (1 << 64) if c >= (1 << 63) else c                                          # python int -> int64 wrap
+        x = x + k * -4658895280553007687 + e * 6364136223846793005 + c
+        for mul in (-4658895280553007687, -7723592293110705685):                         # splitmix64 finaliser
+            x = (x ^ (x >> 30)) * mul
+        x = x ^ (x >> 31)
+        self._perm_calls += 1
+        perm = x.argsort(dim=2).to(torch.int32)
         if steps * self.B != n:   # wrap around: the extra rows are masked out through n_valid
             perm = perm[:, :, torch.arange(steps * self.B) % n]
         return perm.contiguous()
@@ -578,7 +593,7 @@ class HipEngine(ShardEngine):
                 if self.v is not None:
                     self.v.copy_(snap[2])
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):   # RCCL's watchdog thread may query events meanwhile
                     self._train(epochs, steps, n)
                 self._graphs[key] = (g,)
                 self.params.copy_(snap[0]); self.m.copy_(snap[1])
@@ -609,7 +624,7 @@ class HipEngine(ShardEngine):
                 torch.cuda.current_stream().wait_stream(s)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):   # RCCL's watchdog thread may query events meanwhile
                     self._eval_body()
                 self._eval_graph = g
             self._eval_graph.replay()

@@ -82,6 +82,7 @@ class BatchedFederation:
         self.n_local = len(self.local)
         self.engine: ShardEngine = make_engine(spec, self.n_local, self.device, impl=engine, batch_size=batch_size,
                                                seed=seed, persist_optimizer=persist_optimizer,
+                                               client_offset=self.local.start,
                                                **({"use_graph": use_graph, "overlap": overlap} if engine != "eager" else {}))
         # membership of ALL nodes of the scenario (every rank applies the same deterministic schedule)
         self.membership = VirtualMembership(self.N, heartbeat_period, node_timeout, instant=instant_detection)

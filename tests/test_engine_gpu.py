@@ -101,3 +101,57 @@ def test_pipelined_schedule_matches_single_stream():
         rel = ((d - d0).norm() / d0.norm()).item()
         assert rel < 0.05, rel
         assert torch.allclose(tl, out[0][1], atol=1e-2) and torch.allclose(vl, out[0][2], atol=1e-2)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Two ranks sharing the one GPU of the test box (gloo, rows staged through the host): the rank-local index
+# math of the exchange plan + the HIP reduce over local and staged remote rows + per-link device AES must
+# reproduce the single-rank federation. (RCCL refuses two ranks on one device; on a multi-GPU node the same
+# code runs with backend "nccl".)
+def _two_rank_worker(rank, world, port, kind, encrypt, out):
+    import os
+    import torch.distributed as dist
+    from p2pfl_amd.datasets.synthetic import synthetic_shards
+    from p2pfl_amd.models.specs import get_spec
+    from p2pfl_amd.runtime.federation import BatchedFederation
+    from p2pfl_amd.utils.topologymanager import TopologyManager
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fed = _gpu_fed(kind, rank, world, dist.group.WORLD if world > 1 else None, encrypt)
+    for _ in range(2):
+        fed.run_round(evaluate=False)
+    torch.cuda.synchronize()
+    out[rank] = fed.engine.params[:, :4096].cpu()
+    dist.destroy_process_group()
+
+
+def _gpu_fed(kind, rank=0, world=1, pg=None, encrypt=False, n=6):
+    from p2pfl_amd.datasets.synthetic import synthetic_shards
+    from p2pfl_amd.models.specs import get_spec
+    from p2pfl_amd.runtime.federation import BatchedFederation
+    from p2pfl_amd.utils.topologymanager import TopologyManager
+    tm = TopologyManager(n_nodes=n, b_symmetric=True, undirected_neighbor_num=n - 1 if kind == "fully" else 3, seed=3)
+    tm.generate_topology() if kind != "ring" else tm.generate_ring_topology()
+    fed = BatchedFederation(get_spec("mnist-mlp"), tm.topology, device="cuda", engine="hip", epochs=1, seed=2, rank=rank,
+                            world_size=world, process_group=pg, encrypt=encrypt, use_graph=False)
+    fed.init_params()
+    tx, ty, vx, vy, ex, ey = synthetic_shards(n, 64, 16, 32, 10, seed=9, device="cuda")
+    sl = slice(fed.local.start, fed.local.stop)
+    fed.set_local_data(tx[sl], ty[sl], vx[sl], vy[sl], ex[sl], ey[sl])
+    return fed
+
+
+@pytest.mark.parametrize("kind,encrypt", [("ring", False), ("random", True), ("fully", False)])
+def test_two_ranks_on_one_gpu_match_single_rank(kind, encrypt):
+    import socket
+    import torch.multiprocessing as mp
+    ref = _gpu_fed(kind)
+    for _ in range(2):
+        ref.run_round(evaluate=False)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = mp.Manager().dict()
+    mp.spawn(_two_rank_worker, args=(2, port, kind, encrypt, out), nprocs=2, join=True)
+    got = torch.cat([out[0], out[1]], dim=0)
+    want = ref.engine.params[:, :4096].cpu()
+    # bf16-MFMA training is deterministic per node; only FedAvg summation order may differ
+    assert torch.allclose(got, want, atol=1e-5, rtol=1e-4), (got - want).abs().max()

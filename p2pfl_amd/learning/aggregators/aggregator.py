@@ -150,6 +150,12 @@ class Aggregator(Observable):
                 logging.debug("[Aggregator] can't add a model that has already been added %s", nodes)
         return None
 
+    def get_single(self, name):
+        """(model, [name], weight) of the un-aggregated contribution of ``name`` if it is held, else None."""
+        with self._lock:
+            entry = self._models.get(name)
+        return None if entry is None else (entry[0], [name], entry[1])
+
     def is_complete(self, nodes) -> bool:
         """A model a waiting node may adopt as the round's result: diffused (no contributor list) or
         aggregated from at least this node's whole train set (an empty train set accepts anything:

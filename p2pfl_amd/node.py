@@ -249,6 +249,11 @@ class Node(BaseNode):
             decoded, contributors, weight = self.learner.decode_parameters(m)
             if not self.learner.check_parameters(decoded):
                 raise ModelNotMatchingError("Not matching models")
+            if contributors is not None and self._train_set and any(c not in self._train_set for c in contributors):
+                # FedAvg runs over train_set = neighbours U {self} (node.py:411-416): a partial aggregate that carries a
+                # model from outside it (a neighbour's other neighbour, in a ring / random graph) is not ours to average
+                logging.debug("[NODE] refused contributors outside the train set: %s", contributors)
+                return
             waits = Role.waits(self.role)
             with self._round_lock:     # decoding took milliseconds: the round may have advanced meanwhile
                 if payload_round is not None and payload_round != self.round:
@@ -446,7 +451,17 @@ class Node(BaseNode):
                            and (len(nc.get_models_aggregated()) < len(self._train_set)
                                 or me not in nc.get_models_aggregated()))
         status = lambda nc: (nc.get_name(), len(nc.get_models_aggregated()))
-        model = lambda nc: self.aggregator.get_partial_aggregation(nc.get_models_aggregated())
+
+        def model(nc):
+            # Our own contribution goes out on its own first: the peer certainly wants it (we are its neighbour),
+            # whereas a partial aggregate that mixes it with models from outside the peer's train set is refused
+            # there (add_model). Afterwards: the reference's partial aggregation of everything the peer lacks.
+            have = nc.get_models_aggregated()
+            if me not in have:
+                own = self.aggregator.get_single(me)
+                if own is not None:
+                    return own
+            return self.aggregator.get_partial_aggregation(have)
         self._gossip_model(cand, status, model)
 
     def _gossip_model_difusion(self, initialization=False):

@@ -169,3 +169,34 @@ def test_checkpoint_per_round_and_resume(tmp_path):
             fresh.stop()
     finally:
         stop_all(nodes)
+
+
+def test_ring_over_tcp_each_node_averages_exactly_its_train_set():
+    """Sparse topology: every node ends a round with FedAvg over neighbours U {self} - the
+    same fixed point the batched runtime computes - and not with models that leaked in through partial
+    aggregates of its neighbours' neighbours."""
+    n = 5
+    nodes = make_nodes(n, [Role.AGGREGATOR] * n)
+    try:
+        for i in range(n):
+            assert nodes[i].connect_to(nodes[(i + 1) % n].host, nodes[(i + 1) % n].port) is not None
+        time.sleep(0.8)
+        assert all(len(x.get_neighbors()) == 2 for x in nodes)
+        # "training" = add (idx + 1) * 0.01 to every parameter: the expected average is known in closed form
+        for i, x in enumerate(nodes):
+            def fit(x=x, i=i):
+                with torch.no_grad():
+                    for p in x.learner.model.parameters():
+                        p.add_((i + 1) * 0.01)
+            x.learner.fit = fit
+        nodes[0].set_start_learning(rounds=1, epochs=1)
+        assert wait_finished(nodes)
+        base = None
+        for i, x in enumerate(nodes):
+            got = x.learner.get_parameters()["l3.bias"]
+            shift = sum((j % n) + 1 for j in (i - 1, i, i + 1)) * 0.01 / 3
+            if base is None:
+                base = got - shift
+            assert torch.allclose(got - shift, base, atol=1e-6), (i, (got - shift - base).abs().max())
+    finally:
+        stop_all(nodes)

@@ -26,6 +26,7 @@ per-link key and decrypted on arrival (the reference's per-link AES, encrypter.p
 from __future__ import annotations
 
 import hashlib
+import os
 import random
 import time
 from dataclasses import dataclass, field
@@ -93,7 +94,7 @@ class BatchedFederation:
         self.comm = DeviceExchange(rank, world_size, process_group, self.device, encrypt, scenario)
         self.staging: Optional[torch.Tensor] = None
         self._plan_cache: Dict[bytes, tuple] = {}
-        self.trace = bool(int(__import__("os").environ.get("P2PFL_TRACE", "0")))   # roctx ranges around the phases
+        self.trace = os.environ.get("P2PFL_TRACE", "0") not in ("", "0")   # roctx ranges around the phases
         self.reports: List[RoundReport] = []
 
     # ------------------------------------------------------------------ setup

@@ -65,12 +65,19 @@ __global__ __launch_bounds__(256) void conv2_prep_kernel(const float* w, long w_
     const float* src = w + c * w_cs;
     __bf16* wf = wp + c * wp_cs;
     __bf16* wd = wf + T * COUT * CIN;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < COUT * CIN * T; i += gridDim.x * 256) {
-        const int t = i % T, nc = i / T;
-        const int n = nc / CIN, ci = nc % CIN;
-        const __bf16 v = (__bf16)src[i];
-        wf[(t * COUT + n) * CIN + ci] = v;
-        wd[((T - 1 - t) * CIN + ci) * COUT + n] = v;
+    // output-ordered: coalesced bf16 writes, strided (cache-resident) fp32 reads - the input-ordered form
+    // scattered two 2-byte stores per element 4 KB apart (175 -> 101 us for 1000 clients 3x3, 64 -> 41 us for 100 clients 5x5)
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < COUT * CIN * T; o += gridDim.x * 256) {
+        {   // wf[(t * COUT + n) * CIN + ci]
+            const int ci = o % CIN, tn = o / CIN;
+            const int n = tn % COUT, t = tn / COUT;
+            wf[o] = (__bf16)src[(n * CIN + ci) * T + t];
+        }
+        {   // wd[((T - 1 - t) * CIN + ci) * COUT + n]
+            const int n = o % COUT, tc = o / COUT;
+            const int ci = tc % CIN, t = T - 1 - tc / CIN;
+            wd[o] = (__bf16)src[(n * CIN + ci) * T + t];
+        }
     }
 }
 

@@ -179,10 +179,15 @@ __global__ __launch_bounds__(256, 2) void conv2_fwd_kernel(FwdArgs a) {
         if (++kx == KS) { kx = 0; ++ky; }
     }
 
-    // ---- epilogue: bias + ReLU + 2x2 max-pool + arg-max code, straight from the accumulators
+    // ---- epilogue: bias + ReLU + 2x2 max-pool + arg-max code from the accumulators. A lane owns an output
+    // channel, whose pooled cells are 196 B apart in memory: direct stores would be 208 fully scattered
+    // 4-byte / 1-byte store instructions per wave. The block's outputs (S samples x [64][49], one contiguous
+    // 25 KB piece of a2 and 6 KB of codes) are assembled in the now idle image buffer and written as 16-byte
+    // pieces per lane instead.
+    static_assert(S * G::XSS >= S * COUT * CELLS2 * 5, "output staging must fit into the image buffer");
+    float* out_s = reinterpret_cast<float*>(ximg);
+    uint8_t* code_s = ximg + S * COUT * CELLS2 * 4;
     const float* bias = a.bias + c * a.b_cs;
-    float* a2 = a.a2 + c * a.a2_cs;
-    uint8_t* code = a.code + c * a.c_cs;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         if (i >= ntile) continue;
@@ -193,20 +198,27 @@ __global__ __launch_bounds__(256, 2) void conv2_fwd_kernel(FwdArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int W = (wave + 4 * i) * 8 + 2 * g + h;
-                const int s = W / CELLS2, cell = W % CELLS2;
-                if (W >= NWIN || b0 + s >= a.B) continue;
+                if (W >= NWIN) continue;
                 float best = acc[i][j][4 * g]; int q = 0;
                 if (acc[i][j][4 * g + 1] > best) { best = acc[i][j][4 * g + 1]; q = 1; }
                 if (acc[i][j][4 * g + 2] > best) { best = acc[i][j][4 * g + 2]; q = 2; }
                 if (acc[i][j][4 * g + 3] > best) { best = acc[i][j][4 * g + 3]; q = 3; }
                 best += bv;
                 if (!(best > 0.f)) { best = 0.f; q = 4; }
-                const size_t o = ((size_t)(b0 + s) * COUT + n) * CELLS2 + cell;
-                a2[o] = best;
-                code[o] = (uint8_t)q;
+                const int o = ((W / CELLS2) * COUT + n) * CELLS2 + W % CELLS2;     // == the global layout of the block
+                out_s[o] = best;
+                code_s[o] = (uint8_t)q;
             }
         }
     }
+    __syncthreads();
+    const int nvalid = min(S, a.B - b0) * COUT * CELLS2;                          // floats (= code bytes) to write
+    float* a2 = a.a2 + c * a.a2_cs + (size_t)b0 * COUT * CELLS2;
+    uint8_t* code = a.code + c * a.c_cs + (size_t)b0 * COUT * CELLS2;
+    for (int i = tid; i < nvalid / 4; i += 256)
+        reinterpret_cast<f32x4*>(a2)[i] = reinterpret_cast<const f32x4*>(out_s)[i];
+    for (int i = tid; i < nvalid / 16; i += 256)
+        reinterpret_cast<f32x4*>(code)[i] = reinterpret_cast<const f32x4*>(code_s)[i];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -305,6 +317,7 @@ __global__ __launch_bounds__(256, 2) void conv2_dgrad_kernel(DgradArgs a) {
     }
 
     // ---- epilogue: lane = input channel, registers 4g..4g+3 = four consecutive pixels -> float4
+    // (assembling the sample in LDS for address-ordered stores was measured: no gain over these 16-byte pieces)
     float* dst = a.da1 + c * a.da1_cs + ((size_t)b * CIN + r) * CELLS1;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -520,6 +533,7 @@ P2PFL_API int p2pfl_conv2_fwd(const float* a1, long a1_cs, const void* wp, long 
                               int CIN_, int COUT_, int KS, hipStream_t stream) {
     if (K <= 0 || B <= 0 || CIN_ != CIN || COUT_ != COUT) return -1;
     if ((wp_cs & 7) || ((uintptr_t)wp & 15)) return -2;
+    if (((uintptr_t)a2 & 15) || (a2_cs & 3) || ((uintptr_t)code & 15) || (c_cs & 15)) return -2;   // 16-byte block stores
     FwdArgs a{a1, a1_cs, (const __bf16*)wp, wp_cs, bias, b_cs, a2, a2_cs, code, c_cs, K, B};
     dim3 grid(cdiv(K, 8) * 8 * cdiv(B, 2));
     if (KS == 5) hipLaunchKernelGGL(conv2_fwd_kernel<5>, grid, dim3(256), 0, stream, a);

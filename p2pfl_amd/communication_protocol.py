@@ -24,8 +24,7 @@ from __future__ import annotations
 import ctypes
 import logging
 import secrets
-import threading
-from typing import Callable, Dict, List, Optional, Tuple
+from typing import Callable, Dict, List
 
 from .utils import hostlib
 

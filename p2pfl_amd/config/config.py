@@ -9,7 +9,6 @@ key (the reference's ``_set_default_config`` is a stub), light validation, and t
 """
 from __future__ import annotations
 
-import copy
 import json
 import os
 from typing import Any, Dict, List, Optional

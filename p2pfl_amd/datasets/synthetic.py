@@ -8,7 +8,7 @@ rows (mnist/mnist.py:100-118).
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Tuple
 
 import torch
 

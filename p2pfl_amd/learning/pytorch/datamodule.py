@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import logging
 from math import floor
-from typing import Optional, Tuple
+from typing import Tuple
 
 import torch
 from torch.utils.data import DataLoader, TensorDataset

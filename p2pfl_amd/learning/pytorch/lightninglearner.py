@@ -22,7 +22,6 @@ from __future__ import annotations
 import logging
 import threading
 from collections import OrderedDict
-from typing import Optional
 
 import numpy as np
 import torch

@@ -19,7 +19,7 @@ is an all-to-all of per-link ciphertexts followed by a local sum.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Sequence
 
 import torch
 import torch.distributed as dist

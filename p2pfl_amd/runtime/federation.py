@@ -29,18 +29,17 @@ import hashlib
 import os
 import random
 import time
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
-import torch.distributed as dist
 
 from ..models.specs import ModelSpec
 from ..parallel.collectives import DeviceExchange
 from ..parallel.planner import link_key, partition_nodes, plan_exchange  # noqa: F401  (re-exported)
 from ..role import Role, default_roles
-from .aggregation import AggregationPlan, build_plan, plan_from_train_sets, run_plan
+from .aggregation import AggregationPlan, build_plan, run_plan
 from .engine import ShardEngine, make_engine
 from .membership import VirtualMembership
 

@@ -19,7 +19,6 @@ import glob
 import json
 import logging
 import os
-import sys
 import time
 from typing import List
 

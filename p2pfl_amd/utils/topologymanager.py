@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import json
 import random
-from typing import List, Optional, Sequence
+from typing import List, Optional
 
 import numpy as np
 

@@ -365,6 +365,7 @@ struct WgradArgs {
     float* dw;         long dw_cs;     // [K][64][32*T]
     float* db;         long db_cs;     // [K][64]
     int K, B;
+    float* part;       int NS;         // NS > 1: batch split, partials [K][NS][T*64*32 + 64] (see reduce kernel)
 };
 
 template <int KS, int NP>
@@ -380,8 +381,10 @@ __global__ __launch_bounds__(512, 2) void conv2_wgrad_kernel(WgradArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char ximg[XROWS * XRS];
     __shared__ __attribute__((aligned(16))) unsigned char gimg[NPIX * GPS];
 
-    int c, tp;
-    if (!xcd_map(NP, a.K, c, tp)) return;
+    int c, sub;
+    if (!xcd_map(NP * a.NS, a.K, c, sub)) return;
+    const int tp = sub % NP, split = sub / NP;
+    const int b_begin = split * a.B / a.NS, b_end = (split + 1) * a.B / a.NS;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void conv2_wgrad_kernel(WgradArgs a) {
     const int p0 = tp * T / NP, np = (tp + 1) * T / NP - p0;
     const int t_begin = p0 + tg * np / 4;
     const int ntap = p0 + (tg + 1) * np / 4 - t_begin;
-    const bool do_bias = (tp == 0 && tg == 0);
+    const bool do_bias = (tp == 0 && tg == 0);     // wave-uniform
     int toff[NTAP];
 #pragma unroll
     for (int j = 0; j < NTAP; ++j) {
@@ -467,12 +470,12 @@ __global__ __launch_bounds__(512, 2) void conv2_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
-    prefetch(0);
-    for (int item = 0; item < a.B; ++item) {
+    if (b_begin < b_end) prefetch(b_begin);
+    for (int item = b_begin; item < b_end; ++item) {
         __syncthreads();            // everyone finished reading the previous images (or zero-filling)
         commit();
         __syncthreads();
-        if (item + 1 < a.B) prefetch(item + 1);
+        if (item + 1 < b_end) prefetch(item + 1);
 
 #pragma unroll 1
         for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -492,8 +495,26 @@ __global__ __launch_bounds__(512, 2) void conv2_wgrad_kernel(WgradArgs a) {
         }
     }
 
-    float* dw = a.dw + c * a.dw_cs;
     const int ci = lane & 31;
+    if (a.NS > 1) {
+        // partial of this batch split, tap-major [t][n][ci] (a store instruction covers two 128-B runs; the
+        // dW layout costs 64 scattered dwords per instruction: 80 vs 57 us for 10 clients), then the bias
+        float* pw = a.part + ((size_t)c * a.NS + split) * (T * COUT * CIN + COUT);
+#pragma unroll
+        for (int j = 0; j < NTAP; ++j) {
+            if (j < ntap) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    pw[((t_begin + j) * COUT + mt * 32 + mfma_row_(e, lane)) * CIN + ci] = acc[j][e];
+            }
+        }
+        if (do_bias && ci == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) pw[T * COUT * CIN + mt * 32 + mfma_row_(e, lane)] = accb[e];
+        }
+        return;
+    }
+    float* dw = a.dw + c * a.dw_cs;
 #pragma unroll
     for (int j = 0; j < NTAP; ++j) {
         if (j < ntap) {
@@ -509,6 +530,30 @@ __global__ __launch_bounds__(512, 2) void conv2_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) db[mt * 32 + mfma_row_(e, lane)] = accb[e];
     }
+}
+
+// Sum of the NS batch-split partials [t][n][ci] -> dW[n][ci][t], db[n]. One block per (client, n): reads
+// are 128-B runs, the transposition goes through LDS, the CIN*T floats of dW[n] leave as one contiguous run.
+template <int KS>
+__global__ __launch_bounds__(256) void conv2_wgrad_reduce_kernel(WgradArgs a) {
+    constexpr int T = KS * KS, NW = T * COUT * CIN, PW = NW + COUT;
+    __shared__ float tr[CIN * T];
+    const int c = blockIdx.y, n = blockIdx.x;
+    const float* p = a.part + (size_t)c * a.NS * PW;
+    for (int i = threadIdx.x; i < CIN * T; i += 256) {
+        const int t = i / CIN, ci = i % CIN;
+        float s = 0.f;
+        for (int k = 0; k < a.NS; ++k) s += p[(size_t)k * PW + (t * COUT + n) * CIN + ci];
+        tr[ci * T + t] = s;
+    }
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int k = 0; k < a.NS; ++k) s += p[(size_t)k * PW + NW + n];
+        a.db[c * a.db_cs + n] = s;
+    }
+    __syncthreads();
+    float* dw = a.dw + c * a.dw_cs + (size_t)n * CIN * T;
+    for (int i = threadIdx.x; i < CIN * T; i += 256) dw[i] = tr[i];
 }
 
 }  // namespace
@@ -569,18 +614,44 @@ static int num_cus() {
 template <int KS>
 static void launch_wgrad(const WgradArgs& a, int np, hipStream_t stream) {
     const dim3 block(512);
-    if (np == 1) hipLaunchKernelGGL((conv2_wgrad_kernel<KS, 1>), dim3(cdiv(a.K, 8) * 8), block, 0, stream, a);
-    else if (np == 2) hipLaunchKernelGGL((conv2_wgrad_kernel<KS, 2>), dim3(cdiv(a.K, 8) * 8 * 2), block, 0, stream, a);
-    else hipLaunchKernelGGL((conv2_wgrad_kernel<KS, 5>), dim3(cdiv(a.K, 8) * 8 * 5), block, 0, stream, a);
+    const int slots = cdiv(a.K, 8) * 8 * a.NS;
+    if (np == 1) hipLaunchKernelGGL((conv2_wgrad_kernel<KS, 1>), dim3(slots), block, 0, stream, a);
+    else if (np == 2) hipLaunchKernelGGL((conv2_wgrad_kernel<KS, 2>), dim3(slots * 2), block, 0, stream, a);
+    else hipLaunchKernelGGL((conv2_wgrad_kernel<KS, 5>), dim3(slots * 5), block, 0, stream, a);
+    if (a.NS > 1)
+        hipLaunchKernelGGL(conv2_wgrad_reduce_kernel<KS>, dim3(COUT, a.K), dim3(256), 0, stream, a);
+}
+
+// batch splits wanted for K clients: 1 while K * np blocks already give every CU one; else up to 8 so that
+// about two blocks per CU are resident (the kernel walks its samples serially, ~6 us each)
+static int wgrad_splits(int K, int B, int np, int cus) {
+    const int blocks = K * np;
+    if (blocks >= cus) return 1;
+    int ns = (2 * cus) / blocks;
+    ns = ns > 8 ? 8 : ns;
+    ns = ns > B ? B : ns;
+    return ns < 1 ? 1 : ns;
+}
+
+// floats of scratch p2pfl_conv2_wgrad wants for this problem (0: none)
+P2PFL_API long p2pfl_conv2_wgrad_scratch(int K, int B, int KS) {
+    if (K <= 0 || B <= 0) return 0;
+    const int cus = num_cus();
+    const int np = K >= cus ? 1 : (2 * K >= (cus * 3) / 4 ? 2 : 5);
+    const int ns = wgrad_splits(K, B, np, cus);
+    return ns > 1 ? (long)K * ns * (KS * KS * COUT * CIN + COUT) : 0;
 }
 
 P2PFL_API int p2pfl_conv2_wgrad(const float* g, long g_cs, const uint8_t* code, long c_cs, const float* a1,
-                                long a1_cs, float* dw, long dw_cs, float* db, long db_cs, int K, int B,
-                                int CIN_, int COUT_, int KS, hipStream_t stream) {
+                                long a1_cs, float* dw, long dw_cs, float* db, long db_cs, float* scratch,
+                                long scratch_floats, int K, int B, int CIN_, int COUT_, int KS,
+                                hipStream_t stream) {
     if (K <= 0 || B <= 0 || CIN_ != CIN || COUT_ != COUT) return -1;
     const int cus = num_cus();
     const int np = K >= cus ? 1 : (2 * K >= (cus * 3) / 4 ? 2 : 5);   // K * np blocks should fill the CUs
-    WgradArgs a{g, g_cs, code, c_cs, a1, a1_cs, dw, dw_cs, db, db_cs, K, B};
+    int ns = wgrad_splits(K, B, np, cus);
+    if (scratch == nullptr || scratch_floats < (long)K * ns * (KS * KS * COUT * CIN + COUT)) ns = 1;
+    WgradArgs a{g, g_cs, code, c_cs, a1, a1_cs, dw, dw_cs, db, db_cs, K, B, scratch, ns};
     if (KS == 5) launch_wgrad<5>(a, np, stream);
     else if (KS == 3) launch_wgrad<3>(a, np, stream);
     else return -3;

@@ -50,6 +50,63 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(LinearArgs a) {
         sm, al, bl, epi, blockIdx.y * 32, blockIdx.x * 128, 0, a.In);
 }
 
+// Skinny-output layer (Out <= 64: the 10- / 62-class heads). A 32 x Out x In problem per client has one
+// tile, so the LDS pipeline above runs 10..100 blocks that each wait a full HBM latency per k-step (49 us for
+// 2048 -> 10). Here the 16 waves of a block split the reduction, fetch their MFMA fragments straight from
+// global memory with several k-steps in flight, and add their partial tiles up through LDS.
+template <int NT, int U>
+__global__ __launch_bounds__(1024) void linear_fwd_skinny_kernel(LinearArgs a) {
+    __shared__ float red[16][16][64];
+    const int c = blockIdx.z, m0 = blockIdx.y * 32;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, kq = (lane >> 5) * 8;
+    LoadRowMajorK xl{a.x + c * a.x_cs, a.B, a.In, a.In, (bool)(a.vec & 1)};
+    LoadRowMajorK wl{a.w + c * a.w_cs, a.Out, a.In, a.In, (bool)(a.vec & 2)};
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    const int nsteps = (a.In + 15) / 16;           // 16-deep k-steps, dealt round-robin to the waves
+    for (int s0 = wave; s0 < nsteps; s0 += 16 * U) {
+        float xv[U][8], wv[U][NT][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = (s0 + 16 * u) * 16 + kq;  // past the end: the loaders return zeros
+            xl.load8(m0 + r, k, xv[u]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wl.load8(j * 32 + r, k, wv[u][j]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bf16x8 af = pack_bf16x8(xv[u]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pack_bf16x8(wv[u][j]), acc[j], 0, 0, 0);
+        }
+    }
+    float* y = a.y + c * a.y_cs;
+    const float* bias = a.b + c * a.b_cs;
+    const int e_out = threadIdx.x >> 6;            // after the reduction thread (e, lane) owns one output
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        if (j > 0) __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[wave][e][lane] = acc[j][e];
+        __syncthreads();
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += red[w][e_out][lane];
+        const int m = m0 + mfma_row(e_out, lane), n = j * 32 + r;
+        if (m < a.B && n < a.Out) {
+            v += bias[n];
+            if (a.relu) v = fmaxf(v, 0.f);
+            y[(size_t)m * a.Out + n] = v;
+        }
+    }
+}
+
 struct DgradArgs {
     const float* dy; long dy_cs;   // [K][B][Out]
     const float* w;  long w_cs;    // [K][Out][In]
@@ -239,6 +296,17 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_adam_kernel(WgradAdamArgs
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+int num_cus() {
+    static int n = 0;
+    if (n <= 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+    }
+    return n;
+}
+
 }  // namespace
 
 P2PFL_API int p2pfl_linear_wgrad_adam(const float* dy, long dy_cs, const float* x, long x_cs, float* w,
@@ -266,10 +334,19 @@ P2PFL_API int p2pfl_linear_fwd(const float* x, long x_cs, const float* w, long w
     const int xv = !((In & 3) || (x_cs & 3) || ((uintptr_t)x & 15));
     const int wv = !((In & 3) || (w_cs & 3) || ((uintptr_t)w & 15));
     LinearArgs a{x, x_cs, w, w_cs, b, b_cs, y, y_cs, B, In, Out, relu, xv | (wv << 1)};
+    if (Out <= 64 && In >= 512) {
+        const dim3 sgrid(1, cdiv(B, 32), K);
+        if (Out <= 32) hipLaunchKernelGGL((linear_fwd_skinny_kernel<1, 4>), sgrid, dim3(1024), 0, stream, a);
+        else hipLaunchKernelGGL((linear_fwd_skinny_kernel<2, 2>), sgrid, dim3(1024), 0, stream, a);
+        P2PFL_RETURN_LAST_ERROR();
+    }
     dim3 grid(cdiv(Out, 128), cdiv(B, 32), K);
     // long reductions (MNIST-CNN l1: In = 3136) take 64-deep k-steps: half the barriers / twice the bytes in
     // flight per step (100 clients on MI355X: 546 -> 516 us; 128-deep steps cost occupancy: 514-589 us)
-    if (In >= 1024) hipLaunchKernelGGL((linear_fwd_kernel<64, 2>), grid, dim3(256), 0, stream, a);
+    // few clients: at most one block per CU, so the bytes in flight per block bound the bandwidth -> 128-deep
+    const bool sparse_grid = (long)grid.x * grid.y * grid.z <= num_cus() && getenv("P2PFL_NO_BK128") == nullptr;
+    if (In >= 1024 && sparse_grid) hipLaunchKernelGGL((linear_fwd_kernel<128, 2>), grid, dim3(256), 0, stream, a);
+    else if (In >= 1024) hipLaunchKernelGGL((linear_fwd_kernel<64, 2>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((linear_fwd_kernel<32, 2>), grid, dim3(256), 0, stream, a);
     P2PFL_RETURN_LAST_ERROR();
 }
@@ -282,7 +359,9 @@ P2PFL_API int p2pfl_linear_dgrad(const float* dy, long dy_cs, const float* w, lo
     const int vec = !((Out & 3) || (dy_cs & 3) || ((uintptr_t)dy & 15));
     DgradArgs a{dy, dy_cs, w, w_cs, act, act_cs, dx, dx_cs, B, In, Out, vec};
     dim3 grid(cdiv(In, 128), cdiv(B, 32), K);
-    if (Out >= 1024) hipLaunchKernelGGL((linear_dgrad_kernel<64, 2>), grid, dim3(256), 0, stream, a);   // 498 -> 478 us
+    const bool sparse_grid = (long)grid.x * grid.y * grid.z <= num_cus() && getenv("P2PFL_NO_BK128") == nullptr;
+    if (Out >= 1024 && sparse_grid) hipLaunchKernelGGL((linear_dgrad_kernel<128, 2>), grid, dim3(256), 0, stream, a);
+    else if (Out >= 1024) hipLaunchKernelGGL((linear_dgrad_kernel<64, 2>), grid, dim3(256), 0, stream, a);   // 498 -> 478 us
     else hipLaunchKernelGGL((linear_dgrad_kernel<32, 2>), grid, dim3(256), 0, stream, a);
     P2PFL_RETURN_LAST_ERROR();
 }

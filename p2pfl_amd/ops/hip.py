@@ -38,7 +38,7 @@ def load():
             if name.startswith("p2pfl_"):
                 fn = getattr(_lib, name)
                 fn.argtypes = getattr(_Sig, name)
-                fn.restype = c_int
+                fn.restype = c_long if name.endswith("_scratch") else c_int
     return _lib
 
 
@@ -58,7 +58,8 @@ class _Sig:
     p2pfl_conv1_wgrad = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, P]
     p2pfl_conv2_prep = [P, L, P, L, I, I, I, I, P]
     p2pfl_conv2_fwd = [P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, P]
-    p2pfl_conv2_wgrad = [P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, P]
+    p2pfl_conv2_wgrad = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, P]
+    p2pfl_conv2_wgrad_scratch = [I, I, I]
     p2pfl_conv2_dgrad = [P, L, P, L, P, L, P, L, I, I, I, I, I, P]
     p2pfl_softmax_ce = [P, L, P, L, P, L, P, L, P, P, P, P, P, L, I, I, I, P]
     p2pfl_zero_rows = [P, L, I, I, P]
@@ -199,13 +200,29 @@ def conv2_fwd(a1, w, bias, a2, code, ks: int, wprep=None) -> None:
          "conv2_fwd")
 
 
+_wgrad_scratch = {}
+
+
 def conv2_wgrad(g, code, a1, dw, db, ks: int) -> None:
-    """Stage-2 weight/bias gradient: dw [K,Cout,Cin*ks*ks], db [K,Cout] (overwritten)."""
+    """Stage-2 weight/bias gradient: dw [K,Cout,Cin*ks*ks], db [K,Cout] (overwritten).
+
+    With few clients the batch is split over more blocks; their partial sums go through a scratch buffer
+    that is kept per (device, stream) - one call per stream is in flight at a time."""
     K, B, Cout = g.shape[0], g.shape[1], g.shape[2]
     Cin = a1.shape[2]
     (gp, gs), (ap, as_), (wp, ws), (bp, bs) = _pc(g), _pc(a1), _pc(dw), _pc(db)
     cp, cs = _pc(code, torch.uint8)
-    _chk(load().p2pfl_conv2_wgrad(gp, gs, cp, cs, ap, as_, wp, ws, bp, bs, K, B, Cin, Cout, ks, _stream()),
+    lib = load()
+    stream = _stream()
+    need = int(lib.p2pfl_conv2_wgrad_scratch(K, B, ks))
+    sp = 0
+    if need:
+        key = (g.device, int(stream or 0))
+        buf = _wgrad_scratch.get(key)
+        if buf is None or buf.numel() < need:
+            buf = _wgrad_scratch[key] = torch.empty(need, dtype=torch.float32, device=g.device)
+        sp = buf.data_ptr()
+    _chk(lib.p2pfl_conv2_wgrad(gp, gs, cp, cs, ap, as_, wp, ws, bp, bs, sp, need, K, B, Cin, Cout, ks, stream),
          "conv2_wgrad")
 
 

@@ -309,6 +309,9 @@ class HipEngine(ShardEngine):
         self.overlap = bool(overlap) and self.nc > 0 and self.nc in self._fused
         if self.overlap:
             self._side = torch.cuda.Stream(device=dev, priority=int(os.environ.get('P2PFL_SIDE_PRIO', '-1')))
+            # third branch: the stage-2 weight gradient runs beside (stage-2 dgrad -> stage-1 wgrad)
+            self._side2 = (torch.cuda.Stream(device=dev, priority=-1)
+                           if os.environ.get('P2PFL_SIDE2', '1') != '0' else None)
             self._act_pp = [self.act[self.nc - 1], torch.zeros_like(self.act[self.nc - 1])]
 
     # ------------------------------------------------------------------ helpers
@@ -468,17 +471,31 @@ class HipEngine(ShardEngine):
                 hip.conv2_fwd(x, W, b, out, self.code[i], l.ksize, wprep=self.wprep[i])
             x = out
 
-    def _conv_backward(self, data, sidx) -> None:
+    def _conv_backward(self, data, sidx, fork=None) -> None:
+        """Backward pass of the convolution stages on the current stream. ``fork``: a second stream the
+        stage-2 weight gradient is put on - it depends on nothing the data-gradient chain produces, and with
+        few clients neither kernel fills the chip on its own. The current stream waits for it at the end."""
         hip = self.hip
+        cur = torch.cuda.current_stream()
+        forked = False
         for i in range(self.nc - 1, -1, -1):
             l = self.spec.layers[i]
             W, _ = self._w(self.params, l)
             gW, gb = self._w(self.grads, l)
             if l.kind == "conv2pool":
-                hip.conv2_wgrad(self.dact[i], self.code[i], self.act[i - 1], gW, gb, l.ksize)
+                if fork is not None:
+                    # the caller made `fork` wait for the capture's origin stream already (forking it off
+                    # this, itself forked, stream crashed hipStreamEndCapture on ROCm 7.0)
+                    with torch.cuda.stream(fork):
+                        hip.conv2_wgrad(self.dact[i], self.code[i], self.act[i - 1], gW, gb, l.ksize)
+                    forked = True
+                else:
+                    hip.conv2_wgrad(self.dact[i], self.code[i], self.act[i - 1], gW, gb, l.ksize)
                 hip.conv2_dgrad(self.dact[i], self.code[i], W, self.dact[i - 1], l.ksize, wprep=self.wprep[i])
             else:
                 hip.conv1_wgrad(self.dact[i], self.code[i], data, sidx, gW, gb, l.ksize)
+        if forked:
+            cur.wait_stream(fork)
 
     def _dense_step(self, conv_out, labels, sidx, n_valid, step_index: int, side) -> None:
         """Dense layers of one training step on the current stream: forward, loss, backward. ``side`` is
@@ -502,6 +519,8 @@ class HipEngine(ShardEngine):
             hip.linear_dgrad(self.dact[i], W, mask, self.dact[i - 1].flatten(2))
             if i == nc:
                 side.wait_stream(main)
+                if self._side2 is not None:
+                    self._side2.wait_stream(main)
             if i in self._fused:
                 Wb, Mb, Vb = self._w(self.params, l), self._w(self.m, l), self._w(self.v, l)
                 hip.linear_wgrad_adam(self.dact[i], xin, Wb[0], Mb[0], Vb[0], Wb[1], Mb[1], Vb[1], lr=o.lr,
@@ -538,12 +557,14 @@ class HipEngine(ShardEngine):
                 t += 1
                 self._dense_step(self._act_pp[(t - 1) & 1], self.train_y, sidx, nv, t, side)
                 with torch.cuda.stream(side):
-                    self._conv_backward(self.train_x, sidx)
+                    self._conv_backward(self.train_x, sidx, fork=self._side2)
                     self._optim_step(t)
                     if s + 1 < steps:
                         self._conv_forward(self.train_x, self._perm_buf[e, :, (s + 1) * self.B:(s + 2) * self.B],
                                            self._act_pp[t & 1])
                 main.wait_stream(side)
+                if self._side2 is not None:
+                    main.wait_stream(self._side2)
             if self.val_x is not None:
                 self._eval_pass(self.val_x, self.val_y, "Validation")
 

@@ -30,7 +30,7 @@ def strided(K, shape, pad):
     return slab[:, :n].unflatten(1, shape)
 
 
-dims = st.tuples(st.integers(1, 4), st.integers(1, 40), st.integers(1, 300), st.integers(1, 200), st.sampled_from([0, 3, 64]))
+dims = st.tuples(st.integers(1, 4), st.integers(1, 40), st.integers(1, 700), st.integers(1, 200), st.sampled_from([0, 3, 64]))
 
 
 @FUZZ

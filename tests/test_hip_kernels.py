@@ -45,7 +45,10 @@ def route(g, code, P):
 
 
 @pytest.mark.parametrize("K,B,In,Out,relu", [(3, 32, 784, 256, True), (2, 20, 128, 10, False),
-                                             (2, 32, 3136, 2048, True), (1, 5, 36, 7, False)])
+                                             (2, 32, 3136, 2048, True), (1, 5, 36, 7, False),
+                                             # skinny heads (split-reduction kernel): aligned, 2 col tiles, ragged
+                                             (3, 32, 2048, 10, False), (2, 32, 2048, 62, False),
+                                             (2, 45, 1001, 33, True), (1, 7, 515, 64, True)])
 def test_linear_fwd(K, B, In, Out, relu):
     h = hip()
     x = torch.randn(K, B, In, device=DEV)
@@ -174,7 +177,8 @@ def test_conv2_fwd(ks, B, K):
         assert ((a2[k] == 0) == (code[k] == 4)).all()
 
 
-@pytest.mark.parametrize("ks,B,K", [(5, 32, 2), (3, 32, 2), (5, 9, 3), (5, 32, 11), (3, 7, 9)])
+# K = 2..11: batch-split blocks + partial reduction; K = 60 / 130: one block per (client, tap part)
+@pytest.mark.parametrize("ks,B,K", [(5, 32, 2), (3, 32, 2), (5, 9, 3), (5, 32, 11), (3, 7, 9), (5, 4, 60), (3, 3, 130)])
 def test_conv2_wgrad_dgrad(ks, B, K):
     h = hip()
     Cin, Cout = 32, 64
@@ -308,10 +312,14 @@ def test_aes128_ecb_known_answer_and_roundtrip():
     assert bytes(e2[:4096].cpu().tolist()) == ecb_host(key, bytes(big[:4096].cpu().tolist()), decrypt=False)
 
 
+@pytest.mark.parametrize("deep", [True, False])
 @pytest.mark.parametrize("In,Out", [(1024, 96), (1100, 70)])
-def test_linear_long_reduction_variants(In, Out):
-    """In / Out >= 1024 dispatch to the 64-deep k-step kernels (incl. a ragged last step)."""
+def test_linear_long_reduction_variants(In, Out, deep, monkeypatch):
+    """In / Out >= 1024 dispatch to the 64-deep k-step kernels, or to the 128-deep ones when the grid has at
+    most one block per CU (as here; P2PFL_NO_BK128 turns that off) - incl. a ragged last step."""
     from p2pfl_amd.ops import hip
+    if not deep:
+        monkeypatch.setenv("P2PFL_NO_BK128", "1")
     torch.manual_seed(1)
     K, B = 2, 32
     x = torch.randn(K, B, In, device="cuda")

@@ -622,23 +622,30 @@ static void launch_wgrad(const WgradArgs& a, int np, hipStream_t stream) {
         hipLaunchKernelGGL(conv2_wgrad_reduce_kernel<KS>, dim3(COUT, a.K), dim3(256), 0, stream, a);
 }
 
-// batch splits wanted for K clients: 1 while K * np blocks already give every CU one; else up to 8 so that
-// about two blocks per CU are resident (the kernel walks its samples serially, ~6 us each)
-static int wgrad_splits(int K, int B, int np, int cus) {
-    const int blocks = K * np;
-    if (blocks >= cus) return 1;
-    int ns = (2 * cus) / blocks;
-    ns = ns > 8 ? 8 : ns;
-    ns = ns > B ? B : ns;
-    return ns < 1 ? 1 : ns;
+// Work split of the weight gradient for K clients: np tap parts x ns batch splits per client. Every block
+// stages whole images however few taps it owns, so tap parts multiply the staging work while batch splits
+// only add the partial-sum traffic: take the fewest tap parts with which <= 8 batch splits still give every
+// CU a block (aiming at two).  3x3: 1000 clients -> 1 x 1, 50 -> 1 x 8;  5x5: 100 -> 2 x 3, 10 -> 5 x 8.
+// 5x5 with one tap part means 7 accumulator tiles per wave: such a block does not fit on a CU beside the
+// two workgroups of the fused wgrad+Adam kernel it is meant to overlap with (measured: it then waits the
+// whole 3 ms out, headline 237 -> 255 ms), so below one client per CU the 5x5 kernel takes >= 2 parts.
+static void wgrad_split(int K, int B, int KS, int cus, int& np, int& ns) {
+    static const int parts[3] = {1, 2, 5};
+    for (int i = (KS == 5 && K < cus) ? 1 : 0; i < 3; ++i) {
+        np = parts[i];
+        ns = (2 * cus + K * np - 1) / (K * np);
+        ns = ns > 8 ? 8 : ns;
+        ns = ns > B ? B : ns;
+        ns = ns < 1 ? 1 : ns;
+        if ((long)K * np * ns >= cus) return;
+    }
 }
 
 // floats of scratch p2pfl_conv2_wgrad wants for this problem (0: none)
 P2PFL_API long p2pfl_conv2_wgrad_scratch(int K, int B, int KS) {
     if (K <= 0 || B <= 0) return 0;
-    const int cus = num_cus();
-    const int np = K >= cus ? 1 : (2 * K >= (cus * 3) / 4 ? 2 : 5);
-    const int ns = wgrad_splits(K, B, np, cus);
+    int np, ns;
+    wgrad_split(K, B, KS, num_cus(), np, ns);
     return ns > 1 ? (long)K * ns * (KS * KS * COUT * CIN + COUT) : 0;
 }
 
@@ -647,9 +654,8 @@ P2PFL_API int p2pfl_conv2_wgrad(const float* g, long g_cs, const uint8_t* code, 
                                 long scratch_floats, int K, int B, int CIN_, int COUT_, int KS,
                                 hipStream_t stream) {
     if (K <= 0 || B <= 0 || CIN_ != CIN || COUT_ != COUT) return -1;
-    const int cus = num_cus();
-    const int np = K >= cus ? 1 : (2 * K >= (cus * 3) / 4 ? 2 : 5);   // K * np blocks should fill the CUs
-    int ns = wgrad_splits(K, B, np, cus);
+    int np, ns;
+    wgrad_split(K, B, KS, num_cus(), np, ns);
     if (scratch == nullptr || scratch_floats < (long)K * ns * (KS * KS * COUT * CIN + COUT)) ns = 1;
     WgradArgs a{g, g_cs, code, c_cs, a1, a1_cs, dw, dw_cs, db, db_cs, K, B, scratch, ns};
     if (KS == 5) launch_wgrad<5>(a, np, stream);

@@ -54,6 +54,7 @@ class _Sig:
     p2pfl_linear_dgrad = [P, L, P, L, P, L, P, L, I, I, I, I, P]
     p2pfl_linear_wgrad = [P, L, P, L, P, L, P, L, I, I, I, I, P]
     p2pfl_linear_wgrad_adam = [P, L, P, L, P, P, P, L, P, P, P, L, I, I, I, I, F, F, F, F, F, I, P, P]
+    p2pfl_linear_wgrad_sgdm = [P, L, P, L, P, P, L, P, P, L, I, I, I, I, F, F, F, P]
     p2pfl_conv1_fwd = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, P]
     p2pfl_conv1_wgrad = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, P]
     p2pfl_conv2_prep = [P, L, P, L, I, I, I, I, P]
@@ -142,6 +143,19 @@ def linear_wgrad_adam(dy, x, w, mw, vw, b, mb, vb, *, lr, beta1=0.9, beta2=0.999
                                         w.stride(0), _t(b).data_ptr(), _t(mb).data_ptr(), _t(vb).data_ptr(),
                                         b.stride(0), K, B, In, Out, lr, beta1, beta2, eps, weight_decay, t,
                                         None if bc is None else _t(bc).data_ptr(), _stream()), "linear_wgrad_adam")
+
+
+def linear_wgrad_sgdm(dy, x, w, mw, b, mb, *, lr, momentum=0.9, weight_decay=0.0) -> None:
+    """Fused ``dw = dy.T @ x`` + SGD-momentum update of (w, b) and their momentum buffers (same layout rules
+    as :func:`linear_wgrad_adam`)."""
+    K, B, Out = dy.shape
+    In = x.shape[2]
+    assert w.shape == (K, Out, In) and b.shape == (K, Out)
+    assert w.stride(0) == mw.stride(0) and b.stride(0) == mb.stride(0)
+    (dp, ds), (xp, xs) = _pc(dy), _pc(x)
+    _chk(load().p2pfl_linear_wgrad_sgdm(dp, ds, xp, xs, _t(w).data_ptr(), _t(mw).data_ptr(), w.stride(0),
+                                        _t(b).data_ptr(), _t(mb).data_ptr(), b.stride(0), K, B, In, Out, lr,
+                                        momentum, weight_decay, _stream()), "linear_wgrad_sgdm")
 
 
 # ----------------------------------------------------------------------------- conv

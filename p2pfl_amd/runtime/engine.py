@@ -244,6 +244,18 @@ class EagerEngine(ShardEngine):
 # ======================================================================================
 # HIP engine
 # ======================================================================================
+def live_aux_streams():
+    """(role, stream) of every auxiliary HIP stream of the engines alive in this process - for the stall
+    diagnostics (tests/conftest.py, tools/diag_streams.py). Found through the garbage collector on demand: a
+    registry of weak references to the streams crashed the interpreter's final collection with big shards."""
+    import gc
+    out = []
+    for obj in gc.get_objects():
+        if isinstance(obj, HipEngine) and getattr(obj, "overlap", False):
+            out.append(("side", obj._side))
+    return out
+
+
 class HipEngine(ShardEngine):
     """Client-batched gfx950 kernels + hipGraph replay (see module docstring)."""
 
@@ -280,14 +292,17 @@ class HipEngine(ShardEngine):
         self.karange = torch.arange(K, device=dev).unsqueeze(1)
         self._nv_cache: Dict[int, torch.Tensor] = {}
         self._tail_cache: Dict[tuple, torch.Tensor] = {}
-        # big linear layers: weight gradient fused with the Adam update (gradient never hits HBM)
+        # big linear layers: weight gradient fused with the optimizer update (gradient never hits HBM)
         self._fused = set()
-        self._adam_ranges = [(0, L.row_stride)]
-        if o.kind == "adam" and fuse_optimizer:
+        self._adam_ranges = [(0, L.row_stride)]      # slab ranges the element-wise optimizer kernel owns
+        if o.kind in ("adam", "sgd") and fuse_optimizer and not os.environ.get("P2PFL_NO_FUSE"):
             cut = []
             for i, l in enumerate(self.spec.layers):
                 ws, bs = L.by_name[l.weight], L.by_name[l.bias]
-                if l.kind == "linear" and ws.numel >= (1 << 20) and bs.offset == ws.offset + -(-ws.numel // 64) * 64:
+                # per client >= 1 M weights, or a shard of them that no longer fits the 256 MB infinity cache
+                # (50 FEMNIST clients x 0.19 M: the fused kernel is 22 us per step SLOWER than wgrad + SGD)
+                big = ws.numel >= (1 << 20) or (ws.numel >= (1 << 16) and K * ws.numel >= (1 << 26))
+                if l.kind == "linear" and big and bs.offset == ws.offset + -(-ws.numel // 64) * 64:
                     self._fused.add(i)
                     cut.append((ws.offset, bs.offset + -(-bs.numel // 64) * 64))
             ranges, pos = [], 0
@@ -306,13 +321,27 @@ class HipEngine(ShardEngine):
         # behind the convolutions is a big fused wgrad+Adam layer (HBM-bound for milliseconds) under
         # which the MFMA/LDS-bound convolution kernels can hide.
         self.nc = sum(1 for l in self.spec.layers if l.kind != "linear")
-        self.overlap = bool(overlap) and self.nc > 0 and self.nc in self._fused
+        # (FEMNIST-CNN: the head has 0.19 M weights, its fused update takes 0.6 ms for 1000 clients next to
+        # 3.5 ms of MFMA-bound convolutions - overlapped it ran 38..61 ms per round from run to run against a
+        # steady 42 ms in order, so the pipeline is kept for update-dominated models only.)
+        first_dense = self.spec.layers[self.nc] if self.nc < len(self.spec.layers) else None
+        self.overlap = (bool(overlap) and self.nc > 0 and self.nc in self._fused
+                        and L.by_name[first_dense.weight].numel >= (1 << 20))
         if self.overlap:
             self._side = torch.cuda.Stream(device=dev, priority=int(os.environ.get('P2PFL_SIDE_PRIO', '-1')))
-            # third branch: the stage-2 weight gradient runs beside (stage-2 dgrad -> stage-1 wgrad)
-            self._side2 = (torch.cuda.Stream(device=dev, priority=-1)
-                           if os.environ.get('P2PFL_SIDE2', '1') != '0' else None)
+            # (Tried for few clients, where the side chain is as long as the fused update: the stage-2 weight
+            # gradient on a third stream - two same-priority HIP streams waiting for each other deadlocked now
+            # and then, presumably on one shared hardware queue; and on the main stream in front of the fused
+            # update - no gain over the side stream: 10 clients 313 vs 302 ms, 50 FEMNIST clients 54.6 vs 55.3.)
             self._act_pp = [self.act[self.nc - 1], torch.zeros_like(self.act[self.nc - 1])]
+
+    def close(self) -> None:
+        """Release the captured graphs now (while the HIP runtime is certainly alive) instead of at
+        interpreter shutdown."""
+        if self.device.type == "cuda" and (self._graphs or self._eval_graph is not None):
+            torch.cuda.synchronize(self.device)
+        self._graphs.clear()
+        self._eval_graph = None
 
     # ------------------------------------------------------------------ helpers
     def _w(self, slab, l):
@@ -377,13 +406,7 @@ class HipEngine(ShardEngine):
                     hip.linear_dgrad(dy, W, mask, dx)
                     dy_next = self.dact[i - 1]
                 if i in self._fused:
-                    Wb = self._w(self.params, l)
-                    Mb = self._w(self.m, l)
-                    Vb = self._w(self.v, l)
-                    hip.linear_wgrad_adam(dy, xin, Wb[0], Mb[0], Vb[0], Wb[1], Mb[1], Vb[1], lr=o.lr,
-                                          beta1=o.beta1, beta2=o.beta2, eps=o.eps, weight_decay=o.weight_decay,
-                                          t=step_index,
-                                          bc=self._bc_buf[step_index - 1] if self._bc_buf is not None else None)
+                    self._fused_update(l, dy, xin, step_index)
                 else:
                     hip.linear_wgrad(dy, xin, gW, gb)
                 if dy_next is not None:
@@ -395,6 +418,19 @@ class HipEngine(ShardEngine):
             else:  # conv1pool (first layer: no data gradient)
                 hip.conv1_wgrad(dy, self.code[i], data, sidx, gW, gb, l.ksize)
 
+    def _fused_update(self, l, dy, xin, step_index: int) -> None:
+        """Weight gradient of a big linear layer + its optimizer update in one kernel."""
+        o = self.spec.optim
+        Wb, Mb = self._w(self.params, l), self._w(self.m, l)
+        if o.kind == "adam":
+            Vb = self._w(self.v, l)
+            self.hip.linear_wgrad_adam(dy, xin, Wb[0], Mb[0], Vb[0], Wb[1], Mb[1], Vb[1], lr=o.lr, beta1=o.beta1,
+                                       beta2=o.beta2, eps=o.eps, weight_decay=o.weight_decay, t=step_index,
+                                       bc=self._bc_buf[step_index - 1] if self._bc_buf is not None else None)
+        else:
+            self.hip.linear_wgrad_sgdm(dy, xin, Wb[0], Mb[0], Wb[1], Mb[1], lr=o.lr, momentum=o.momentum,
+                                       weight_decay=o.weight_decay)
+
     def _optim_step(self, step_index: int) -> None:
         o = self.spec.optim
         if o.kind == "adam":
@@ -404,8 +440,9 @@ class HipEngine(ShardEngine):
                                    t=step_index,
                                    bc=self._bc_buf[step_index - 1] if self._bc_buf is not None else None)
         else:
-            self.hip.sgdm_step(self.params, self.grads, self.m, lr=o.lr, momentum=o.momentum,
-                               weight_decay=o.weight_decay)
+            for a, b in self._adam_ranges:
+                self.hip.sgdm_step(self.params[:, a:b], self.grads[:, a:b], self.m[:, a:b], lr=o.lr,
+                                   momentum=o.momentum, weight_decay=o.weight_decay)
 
     # ------------------------------------------------------------------ epochs
     def _nv(self, value: int) -> torch.Tensor:
@@ -471,36 +508,23 @@ class HipEngine(ShardEngine):
                 hip.conv2_fwd(x, W, b, out, self.code[i], l.ksize, wprep=self.wprep[i])
             x = out
 
-    def _conv_backward(self, data, sidx, fork=None) -> None:
-        """Backward pass of the convolution stages on the current stream. ``fork``: a second stream the
-        stage-2 weight gradient is put on - it depends on nothing the data-gradient chain produces, and with
-        few clients neither kernel fills the chip on its own. The current stream waits for it at the end."""
+    def _conv_backward(self, data, sidx) -> None:
         hip = self.hip
-        cur = torch.cuda.current_stream()
-        forked = False
         for i in range(self.nc - 1, -1, -1):
             l = self.spec.layers[i]
             W, _ = self._w(self.params, l)
             gW, gb = self._w(self.grads, l)
             if l.kind == "conv2pool":
-                if fork is not None:
-                    # the caller made `fork` wait for the capture's origin stream already (forking it off
-                    # this, itself forked, stream crashed hipStreamEndCapture on ROCm 7.0)
-                    with torch.cuda.stream(fork):
-                        hip.conv2_wgrad(self.dact[i], self.code[i], self.act[i - 1], gW, gb, l.ksize)
-                    forked = True
-                else:
-                    hip.conv2_wgrad(self.dact[i], self.code[i], self.act[i - 1], gW, gb, l.ksize)
+                hip.conv2_wgrad(self.dact[i], self.code[i], self.act[i - 1], gW, gb, l.ksize)
                 hip.conv2_dgrad(self.dact[i], self.code[i], W, self.dact[i - 1], l.ksize, wprep=self.wprep[i])
             else:
                 hip.conv1_wgrad(self.dact[i], self.code[i], data, sidx, gW, gb, l.ksize)
-        if forked:
-            cur.wait_stream(fork)
 
     def _dense_step(self, conv_out, labels, sidx, n_valid, step_index: int, side) -> None:
         """Dense layers of one training step on the current stream: forward, loss, backward. ``side`` is
         released (it may start the convolution backward pass) as soon as the data gradient of the first
-        dense layer exists, i.e. BEFORE that layer's long fused wgrad+Adam kernel is enqueued."""
+        dense layer exists, i.e. BEFORE that layer's long fused wgrad+optimizer kernel is enqueued.
+        """
         hip, layers, nc, o = self.hip, self.spec.layers, self.nc, self.spec.optim
         main = torch.cuda.current_stream()
         x = conv_out.flatten(2)
@@ -519,13 +543,8 @@ class HipEngine(ShardEngine):
             hip.linear_dgrad(self.dact[i], W, mask, self.dact[i - 1].flatten(2))
             if i == nc:
                 side.wait_stream(main)
-                if self._side2 is not None:
-                    self._side2.wait_stream(main)
             if i in self._fused:
-                Wb, Mb, Vb = self._w(self.params, l), self._w(self.m, l), self._w(self.v, l)
-                hip.linear_wgrad_adam(self.dact[i], xin, Wb[0], Mb[0], Vb[0], Wb[1], Mb[1], Vb[1], lr=o.lr,
-                                      beta1=o.beta1, beta2=o.beta2, eps=o.eps, weight_decay=o.weight_decay,
-                                      t=step_index, bc=self._bc_buf[step_index - 1])
+                self._fused_update(l, self.dact[i], xin, step_index)
             else:
                 gW, gb = self._w(self.grads, l)
                 hip.linear_wgrad(self.dact[i], xin, gW, gb)
@@ -557,14 +576,12 @@ class HipEngine(ShardEngine):
                 t += 1
                 self._dense_step(self._act_pp[(t - 1) & 1], self.train_y, sidx, nv, t, side)
                 with torch.cuda.stream(side):
-                    self._conv_backward(self.train_x, sidx, fork=self._side2)
+                    self._conv_backward(self.train_x, sidx)
                     self._optim_step(t)
                     if s + 1 < steps:
                         self._conv_forward(self.train_x, self._perm_buf[e, :, (s + 1) * self.B:(s + 2) * self.B],
                                            self._act_pp[t & 1])
                 main.wait_stream(side)
-                if self._side2 is not None:
-                    main.wait_stream(self._side2)
             if self.val_x is not None:
                 self._eval_pass(self.val_x, self.val_y, "Validation")
 
@@ -603,6 +620,8 @@ class HipEngine(ShardEngine):
             key = (epochs, steps, n)
             if key not in self._graphs:
                 # warm-up on a side stream (lazy module loads, allocator), then capture
+                # (a fresh stream per capture: with one long-lived warm-up stream the parallel branch of the
+                # captured graph ended up on the hardware queue of the launch stream - headline 237 -> 259 ms)
                 s = torch.cuda.Stream(device=self.device)
                 s.wait_stream(torch.cuda.current_stream())
                 snap = (self.params.clone(), self.m.clone(), None if self.v is None else self.v.clone())

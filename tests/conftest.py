@@ -23,3 +23,37 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _stream_watchdog(request):
+    """P2PFL_STREAM_WATCHDOG=<seconds>: if a GPU test runs longer, report which HIP streams still hold work
+    (the engine's auxiliary streams and the default stream) and leave - a stalled device wait cannot be
+    interrupted from Python otherwise."""
+    limit = float(os.environ.get("P2PFL_STREAM_WATCHDOG", "0") or 0)
+    if limit <= 0 or "gpu" not in request.keywords:
+        yield
+        return
+    import threading
+    import time
+
+    import torch
+
+    from p2pfl_amd.runtime import engine as E
+    done = threading.Event()
+
+    def watch():
+        if done.wait(limit):
+            return
+        print(f"\nSTALL in {request.node.nodeid}", flush=True)
+        for role, st in E.live_aux_streams():
+            print("  stream", role, "idle" if st.query() else "BUSY", flush=True)
+        print("  default stream", "idle" if torch.cuda.default_stream().query() else "BUSY", flush=True)
+        import faulthandler
+        faulthandler.dump_traceback()
+        os._exit(3)
+
+    t = threading.Thread(target=watch, daemon=True)
+    t.start()
+    yield
+    done.set()

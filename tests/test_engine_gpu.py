@@ -66,6 +66,32 @@ def test_training_tracks_eager_engine(name, graph):
     assert rh["Validation"]["count"].tolist() == [16] * h.K
 
 
+def test_fused_sgd_for_many_femnist_clients():
+    """With enough clients the FEMNIST head (3136 -> 62) takes the fused wgrad+SGD-momentum kernel (in order:
+    the two-stream schedule is for update-dominated models); the result must match the un-fused engine."""
+    from p2pfl_amd.datasets.synthetic import synthetic_shards
+    from p2pfl_amd.models.specs import get_spec
+    from p2pfl_amd.runtime.engine import HipEngine
+    spec = get_spec("femnist-cnn")
+    K = 352           # 352 x 194 432 weights > 2**26: the fused path
+    data = synthetic_shards(K, 64, 16, 20, spec.num_classes, seed=5, device="cuda")
+    res = []
+    for fuse, graph in ((False, False), (True, False), (True, True)):
+        h = HipEngine(spec, K, "cuda", seed=7, use_graph=graph, fuse_optimizer=fuse)
+        assert not h.overlap and bool(h._fused) == fuse
+        h.init_params(identical=False)
+        p0 = h.params.clone()
+        h.set_data(*data)
+        h.fit(2)
+        r = h.fit(2)
+        torch.cuda.synchronize()
+        res.append((h.params - p0, r["Train"]["loss"]))
+    for d, tl in res[1:]:
+        rel = ((d - res[0][0]).norm() / res[0][0].norm()).item()
+        assert rel < 0.05, rel
+        assert torch.allclose(tl, res[0][1], atol=1e-2)
+
+
 def test_inactive_clients_keep_their_model():
     spec, h, e = _pair("mnist-mlp")
     before = h.params.clone()

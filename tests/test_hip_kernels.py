@@ -111,6 +111,30 @@ def test_linear_wgrad_adam_matches_unfused(K, B, In, Out):
         assert torch.allclose(a, r, atol=1e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize("K,B,In,Out", [(2, 32, 3136, 62), (3, 20, 130, 70), (2, 32, 256, 128)])
+def test_linear_wgrad_sgdm_matches_unfused(K, B, In, Out):
+    """Fused weight gradient + SGD-momentum (with weight decay) == wgrad kernel followed by sgdm_step."""
+    h = hip()
+    P = In * Out + 64 - (In * Out) % 64 + 512
+    slabs = [torch.randn(K, P, device=DEV) * 0.05 for _ in range(2)]
+    slabs[1].zero_()
+    ref = [s.clone() for s in slabs]
+    grads = torch.zeros(K, P, device=DEV)
+    n = In * Out
+    view = lambda s: (s[:, :n].unflatten(1, (Out, In)), s[:, P - 512:P - 512 + Out])
+    for t in range(1, 4):
+        dy = torch.randn(K, B, Out, device=DEV)
+        x = torch.randn(K, B, In, device=DEV)
+        (w, b), (mw, mb) = view(slabs[0]), view(slabs[1])
+        h.linear_wgrad_sgdm(dy, x, w, mw, b, mb, lr=1e-2, momentum=0.9, weight_decay=1e-3)
+        gw, gb = view(grads)
+        h.linear_wgrad(dy, x, gw, gb)
+        h.sgdm_step(ref[0], grads, ref[1], lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    for a, r in zip(slabs, ref):     # (weight decay also moves the unused slab columns of the reference)
+        for va, vr in zip(view(a), view(r)):
+            assert torch.allclose(va, vr, atol=1e-5 * float(vr.abs().max()), rtol=1e-5)
+
+
 @pytest.mark.parametrize("ks,B,Fm", [(5, 32, 32), (7, 32, 32), (5, 7, 32), (7, 13, 20)])
 def test_conv1_fwd(ks, B, Fm):
     h = hip()

@@ -274,21 +274,15 @@ class HipEngine(ShardEngine):
         self.m = L.alloc(K, dev)
         self.v = L.alloc(K, dev) if o.kind == "adam" else None
         # activations / activation gradients / pool codes per layer
-        self.act, self.dact, self.code = [], [], []
-        for l in self.spec.layers:
-            if l.kind == "conv1pool":
-                shp = (K, B, l.cout, 196)
-            elif l.kind == "conv2pool":
-                shp = (K, B, l.cout, 49)
-            else:
-                shp = (K, B, l.out_features)
-            self.act.append(torch.zeros(shp, device=dev))
-            self.dact.append(torch.zeros(shp, device=dev))
-            self.code.append(torch.zeros(shp, dtype=torch.uint8, device=dev) if l.kind != "linear" else None)
+        self.act, self.code = self._alloc_acts(B)
+        self.dact = [torch.zeros_like(a) for a in self.act]
+        # evaluation runs with its own, larger batch (forward only: no gradient buffers) so that the big
+        # dense layer streams its weights once per up to EVAL_B rows instead of once per 32
+        self._eval_bufs: Dict[int, tuple] = {}
         # tap-major bf16 weight copies of the stage-2 convolutions (refreshed at every forward pass)
         self.wprep = {i: hip.conv2_prep_alloc(K, l.ksize, dev) for i, l in enumerate(self.spec.layers)
                       if l.kind == "conv2pool"}
-        self.xin = torch.zeros(K, B, 784, device=dev) if self.spec.layers[0].kind == "linear" else None
+        self.xin = self._alloc_xin(B)
         self.karange = torch.arange(K, device=dev).unsqueeze(1)
         self._nv_cache: Dict[int, torch.Tensor] = {}
         self._tail_cache: Dict[tuple, torch.Tensor] = {}
@@ -343,6 +337,36 @@ class HipEngine(ShardEngine):
         self._graphs.clear()
         self._eval_graph = None
 
+    EVAL_B = 256
+
+    def _alloc_acts(self, B: int):
+        act, code = [], []
+        for l in self.spec.layers:
+            if l.kind == "conv1pool":
+                shp = (self.K, B, l.cout, 196)
+            elif l.kind == "conv2pool":
+                shp = (self.K, B, l.cout, 49)
+            else:
+                shp = (self.K, B, l.out_features)
+            act.append(torch.zeros(shp, device=self.device))
+            code.append(torch.zeros(shp, dtype=torch.uint8, device=self.device) if l.kind != "linear" else None)
+        return act, code
+
+    def _alloc_xin(self, B: int):
+        return torch.zeros(self.K, B, 784, device=self.device) if self.spec.layers[0].kind == "linear" else None
+
+    def _eval_batch(self, n: int) -> int:
+        """Rows per evaluation pass over a split of n samples: a multiple of 32, at least the training batch."""
+        return max(self.B, min(self.EVAL_B, -(-n // 32) * 32))
+
+    def _bufs(self, B: int):
+        """(act, code, xin, B) for batch size B (the training buffers, or lazily made evaluation ones)."""
+        if B == self.B:
+            return self.act, self.code, self.xin, B
+        if B not in self._eval_bufs:
+            self._eval_bufs[B] = self._alloc_acts(B) + (self._alloc_xin(B), B)
+        return self._eval_bufs[B]
+
     # ------------------------------------------------------------------ helpers
     def _w(self, slab, l):
         return self.layout.view2d(slab, l.weight), self.layout.view(slab, l.bias)
@@ -362,25 +386,27 @@ class HipEngine(ShardEngine):
         self._eval_graph = None
 
     # ------------------------------------------------------------------ one batch
-    def _forward(self, data, sidx, labels, n_valid, phase: str, train: bool) -> None:
+    def _forward(self, data, sidx, labels, n_valid, phase: str, train: bool, bufs=None, prep: bool = True) -> None:
         hip, layers = self.hip, self.spec.layers
+        act, code, xin, B = bufs if bufs is not None else (self.act, self.code, self.xin, self.B)
         x = None
         for i, l in enumerate(layers):
             W, b = self._w(self.params, l)
             if l.kind == "conv1pool":
-                hip.conv1_fwd(data, sidx, W, b, self.act[i], self.code[i], l.ksize)
+                hip.conv1_fwd(data, sidx, W, b, act[i], code[i], l.ksize)
             elif l.kind == "conv2pool":
-                hip.conv2_prep(W, self.wprep[i], l.ksize)
-                hip.conv2_fwd(x, W, b, self.act[i], self.code[i], l.ksize, wprep=self.wprep[i])
+                if prep:     # (the weights do not change between the passes of one evaluation)
+                    hip.conv2_prep(W, self.wprep[i], l.ksize)
+                hip.conv2_fwd(x, W, b, act[i], code[i], l.ksize, wprep=self.wprep[i])
             else:
                 if x is None:
                     if sidx is None:
-                        x = data[:, :self.B]
+                        x = data[:, :B]
                     else:
-                        self.xin.copy_(data[self.karange, sidx.long()])
-                        x = self.xin
-                hip.linear_fwd(x.flatten(2) if x.dim() > 3 else x, W, b, self.act[i], l.relu)
-            x = self.act[i]
+                        xin.copy_(data[self.karange, sidx.long()])
+                        x = xin
+                hip.linear_fwd(x.flatten(2) if x.dim() > 3 else x, W, b, act[i], l.relu)
+            x = act[i]
         st = self.stats[phase]
         hip.softmax_ce(x, labels, sidx, self.dact[-1] if train else None, st.loss_sum, st.correct, st.count,
                        st.confusion, n_valid)
@@ -453,25 +479,28 @@ class HipEngine(ShardEngine):
             self._nv_cache[value] = t
         return t
 
-    def _tail_sidx(self, n: int, nb: int) -> torch.Tensor:
+    def _tail_sidx(self, n: int, nb: int, B: int) -> torch.Tensor:
         """Index list of the last partial evaluation batch: nb real rows, then clamped padding rows
         (masked through n_valid) so every access stays inside the allocation."""
-        key = (n, nb)
+        key = (n, nb, B)
         t = self._tail_cache.get(key)
         if t is None:
-            idx = torch.arange(n - nb, n - nb + self.B, device=self.device).clamp(max=n - 1).to(torch.int32)
+            idx = torch.arange(n - nb, n - nb + B, device=self.device).clamp(max=n - 1).to(torch.int32)
             t = idx.unsqueeze(0).expand(self.K, -1).contiguous()
             self._tail_cache[key] = t
         return t
 
     def _eval_pass(self, x, y, phase: str) -> None:
         n = x.shape[1]
-        for s in range(0, n, self.B):
-            nb = min(self.B, n - s)
-            if nb == self.B:
-                self._forward(x[:, s:], None, y[:, s:], self._nv(self.B), phase, train=False)
+        B = self._eval_batch(n)
+        bufs = self._bufs(B)
+        for s in range(0, n, B):
+            nb = min(B, n - s)
+            if nb == B:
+                self._forward(x[:, s:], None, y[:, s:], self._nv(B), phase, train=False, bufs=bufs, prep=s == 0)
             else:
-                self._forward(x, self._tail_sidx(n, nb), y, self._nv(nb), phase, train=False)
+                self._forward(x, self._tail_sidx(n, nb, B), y, self._nv(nb), phase, train=False, bufs=bufs,
+                              prep=s == 0)
 
     def _train_body(self, epochs: int, steps: int, n: int) -> None:
         """Everything a local-training round launches (captured into one hipGraph)."""

@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(WgradArgs a) {
 struct AdamHyper {
     float lr, beta1, beta2, eps, weight_decay, inv_bc1, inv_sqrt_bc2;
     const float* bc;   // optional device {inv_bc1, inv_sqrt_bc2}
+    int fresh;
 };
 
 struct EpiWgradAdam {
@@ -228,11 +229,12 @@ struct EpiWgradAdam {
     float* b; float* mb; float* vb;     // [M] bias and its moments (column N of the product)
     int M, N;
     float step, beta1, beta2, eps, wd, isb2;
+    bool fresh;                          // first step of a new optimizer: the moments are zero, do not read them
     __device__ __forceinline__ void upd(float* p, float* m, float* v, float g) const {
         const float pv = *p;
         g += wd * pv;
-        const float mv = beta1 * (*m) + (1.f - beta1) * g;
-        const float vv = beta2 * (*v) + (1.f - beta2) * g * g;
+        const float mv = beta1 * (fresh ? 0.f : *m) + (1.f - beta1) * g;
+        const float vv = beta2 * (fresh ? 0.f : *v) + (1.f - beta2) * g * g;
         *m = mv; *v = vv;
         *p = pv - step * (mv / (sqrtf(vv) * isb2 + eps));
     }
@@ -243,8 +245,11 @@ struct EpiWgradAdam {
             // MI355X, 100 clients x 3136x2048: 2.96 ms plain, 3.09 nt loads only, 2.88 nt loads + stores)
             const size_t o = (size_t)m * N + n;
             f32x4 pv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + o));
-            f32x4 mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mw + o));
-            f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vw + o));
+            f32x4 mv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (!fresh) {
+                mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mw + o));
+                vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vw + o));
+            }
             const float* gg = &g.x;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_adam_kernel(WgradAdamArgs
     const float isb2 = a.h.bc ? a.h.bc[1] : a.h.inv_sqrt_bc2;
     const long wo = c * a.w_cs, bo = c * a.b_cs;
     EpiWgradAdam epi{a.w + wo, a.mw + wo, a.vw + wo, a.b + bo, a.mb + bo, a.vb + bo, a.Out, a.In,
-                         a.h.lr * ib1, a.h.beta1, a.h.beta2, a.h.eps, a.h.weight_decay, isb2};
+                         a.h.lr * ib1, a.h.beta1, a.h.beta2, a.h.eps, a.h.weight_decay, isb2, a.h.fresh != 0};
     gemm_block_tile<BM, BN, WR, WC, LoadColMajorK, LoadXTOnes, EpiWgradAdam, true, 1>(
         sm, al, bl, epi, blockIdx.y * BM, blockIdx.x * BN, 0, a.B);
 }
@@ -302,9 +307,10 @@ struct EpiWgradSgdm {
     float* w; float* mw; float* b; float* mb;
     int M, N;
     float lr, momentum, wd;
+    bool fresh;
     __device__ __forceinline__ void upd(float* p, float* m, float g) const {
         const float pv = *p;
-        const float mv = momentum * (*m) + (g + wd * pv);
+        const float mv = momentum * (fresh ? 0.f : *m) + (g + wd * pv);
         *m = mv;
         *p = pv - lr * mv;
     }
@@ -313,7 +319,8 @@ struct EpiWgradSgdm {
         if (n + 3 < N && (N & 3) == 0) {
             const size_t o = (size_t)m * N + n;
             f32x4 pv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + o));
-            f32x4 mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mw + o));
+            f32x4 mv = {0.f, 0.f, 0.f, 0.f};
+            if (!fresh) mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mw + o));
             const float* gg = &g.x;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -340,6 +347,7 @@ struct WgradSgdmArgs {
     float* b; float* mb; long b_cs;
     int B, In, Out;
     float lr, momentum, weight_decay;
+    int fresh;
 };
 
 __global__ __launch_bounds__(256, 2) void linear_wgrad_sgdm_kernel(WgradSgdmArgs a) {
@@ -348,7 +356,8 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_sgdm_kernel(WgradSgdmArgs
     LoadColMajorK al{a.dy + c * a.dy_cs, a.Out, a.B, a.Out};
     LoadXTOnes bl{a.x + c * a.x_cs, a.In, a.B};
     const long wo = c * a.w_cs, bo = c * a.b_cs;
-    EpiWgradSgdm epi{a.w + wo, a.mw + wo, a.b + bo, a.mb + bo, a.Out, a.In, a.lr, a.momentum, a.weight_decay};
+    EpiWgradSgdm epi{a.w + wo, a.mw + wo, a.b + bo, a.mb + bo, a.Out, a.In, a.lr, a.momentum, a.weight_decay,
+                     a.fresh != 0};
     gemm_block_tile<128, 128, 4, 1, LoadColMajorK, LoadXTOnes, EpiWgradSgdm, true, 1>(
         sm, al, bl, epi, blockIdx.y * 128, blockIdx.x * 128, 0, a.B);
 }
@@ -372,12 +381,12 @@ P2PFL_API int p2pfl_linear_wgrad_adam(const float* dy, long dy_cs, const float* 
                                       float* mw, float* vw, long w_cs, float* b, float* mb, float* vb,
                                       long b_cs, int K, int B, int In, int Out, float lr, float beta1,
                                       float beta2, float eps, float weight_decay, int t, const float* bc,
-                                      hipStream_t stream) {
+                                      int fresh, hipStream_t stream) {
     if (K <= 0 || B <= 0 || In <= 0 || Out <= 0 || t <= 0) return -1;
     const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
     WgradAdamArgs a{dy, dy_cs, x, x_cs, w, mw, vw, w_cs, b, mb, vb, b_cs, B, In, Out,
                     AdamHyper{lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
-                              (float)(1.0 / sqrt(bc2)), bc}};
+                              (float)(1.0 / sqrt(bc2)), bc, fresh}};
     // 128 x 128 tiles, 2 workgroups per CU: measured best of {128x128, 64x256, 32x512} x {2, 3, 4 per CU}
     // (2.87 / 2.90 / 3.31 ms and 2.87 / 2.99 / 4.09 ms for 100 clients x 3136x2048 on MI355X)
     const dim3 grid(cdiv(In + 1, 128), cdiv(Out, 128), K);
@@ -388,9 +397,9 @@ P2PFL_API int p2pfl_linear_wgrad_adam(const float* dy, long dy_cs, const float* 
 P2PFL_API int p2pfl_linear_wgrad_sgdm(const float* dy, long dy_cs, const float* x, long x_cs, float* w,
                                       float* mw, long w_cs, float* b, float* mb, long b_cs, int K, int B,
                                       int In, int Out, float lr, float momentum, float weight_decay,
-                                      hipStream_t stream) {
+                                      int fresh, hipStream_t stream) {
     if (K <= 0 || B <= 0 || In <= 0 || Out <= 0) return -1;
-    WgradSgdmArgs a{dy, dy_cs, x, x_cs, w, mw, w_cs, b, mb, b_cs, B, In, Out, lr, momentum, weight_decay};
+    WgradSgdmArgs a{dy, dy_cs, x, x_cs, w, mw, w_cs, b, mb, b_cs, B, In, Out, lr, momentum, weight_decay, fresh};
     const dim3 grid(cdiv(In + 1, 128), cdiv(Out, 128), K);
     hipLaunchKernelGGL(linear_wgrad_sgdm_kernel, grid, dim3(256), 0, stream, a);
     P2PFL_RETURN_LAST_ERROR();

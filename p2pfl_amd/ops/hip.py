@@ -53,8 +53,8 @@ class _Sig:
     p2pfl_linear_fwd = [P, L, P, L, P, L, P, L, I, I, I, I, I, P]
     p2pfl_linear_dgrad = [P, L, P, L, P, L, P, L, I, I, I, I, P]
     p2pfl_linear_wgrad = [P, L, P, L, P, L, P, L, I, I, I, I, P]
-    p2pfl_linear_wgrad_adam = [P, L, P, L, P, P, P, L, P, P, P, L, I, I, I, I, F, F, F, F, F, I, P, P]
-    p2pfl_linear_wgrad_sgdm = [P, L, P, L, P, P, L, P, P, L, I, I, I, I, F, F, F, P]
+    p2pfl_linear_wgrad_adam = [P, L, P, L, P, P, P, L, P, P, P, L, I, I, I, I, F, F, F, F, F, I, P, I, P]
+    p2pfl_linear_wgrad_sgdm = [P, L, P, L, P, P, L, P, P, L, I, I, I, I, F, F, F, I, P]
     p2pfl_conv1_fwd = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, P]
     p2pfl_conv1_wgrad = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, P]
     p2pfl_conv2_prep = [P, L, P, L, I, I, I, I, P]
@@ -131,9 +131,10 @@ def linear_wgrad(dy, x, dw, db) -> None:
 
 
 def linear_wgrad_adam(dy, x, w, mw, vw, b, mb, vb, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
-                      t: int, bc=None) -> None:
+                      t: int, bc=None, fresh: bool = False) -> None:
     """Fused ``dw = dy.T @ x`` + Adam update of (w, b) and their moments; the gradient is never
-    written to memory. w/mw/vw are [K,Out,In] slab views with one common row stride, b/mb/vb [K,Out]."""
+    written to memory. w/mw/vw are [K,Out,In] slab views with one common row stride, b/mb/vb [K,Out].
+    ``fresh``: first step of a new optimizer - the moments count as zero and are not read (only written)."""
     K, B, Out = dy.shape
     In = x.shape[2]
     assert w.shape == (K, Out, In) and b.shape == (K, Out)
@@ -142,10 +143,11 @@ def linear_wgrad_adam(dy, x, w, mw, vw, b, mb, vb, *, lr, beta1=0.9, beta2=0.999
     _chk(load().p2pfl_linear_wgrad_adam(dp, ds, xp, xs, _t(w).data_ptr(), _t(mw).data_ptr(), _t(vw).data_ptr(),
                                         w.stride(0), _t(b).data_ptr(), _t(mb).data_ptr(), _t(vb).data_ptr(),
                                         b.stride(0), K, B, In, Out, lr, beta1, beta2, eps, weight_decay, t,
-                                        None if bc is None else _t(bc).data_ptr(), _stream()), "linear_wgrad_adam")
+                                        None if bc is None else _t(bc).data_ptr(), int(fresh), _stream()),
+         "linear_wgrad_adam")
 
 
-def linear_wgrad_sgdm(dy, x, w, mw, b, mb, *, lr, momentum=0.9, weight_decay=0.0) -> None:
+def linear_wgrad_sgdm(dy, x, w, mw, b, mb, *, lr, momentum=0.9, weight_decay=0.0, fresh: bool = False) -> None:
     """Fused ``dw = dy.T @ x`` + SGD-momentum update of (w, b) and their momentum buffers (same layout rules
     as :func:`linear_wgrad_adam`)."""
     K, B, Out = dy.shape
@@ -155,7 +157,7 @@ def linear_wgrad_sgdm(dy, x, w, mw, b, mb, *, lr, momentum=0.9, weight_decay=0.0
     (dp, ds), (xp, xs) = _pc(dy), _pc(x)
     _chk(load().p2pfl_linear_wgrad_sgdm(dp, ds, xp, xs, _t(w).data_ptr(), _t(mw).data_ptr(), w.stride(0),
                                         _t(b).data_ptr(), _t(mb).data_ptr(), b.stride(0), K, B, In, Out, lr,
-                                        momentum, weight_decay, _stream()), "linear_wgrad_sgdm")
+                                        momentum, weight_decay, int(fresh), _stream()), "linear_wgrad_sgdm")
 
 
 # ----------------------------------------------------------------------------- conv

@@ -372,9 +372,13 @@ class HipEngine(ShardEngine):
         return self.layout.view2d(slab, l.weight), self.layout.view(slab, l.bias)
 
     def reset_optimizer(self) -> None:
-        self.m.zero_()
-        if self.v is not None:
-            self.v.zero_()
+        # moments of the fused layers are not cleared when every round starts a new optimizer: their first
+        # fused step overwrites them without reading (saves two passes over the biggest tensors per round)
+        ranges = self._adam_ranges if (self._fused and not self.persist_optimizer) else [(0, self.layout.row_stride)]
+        for a, b in ranges:
+            self.m[:, a:b].zero_()
+            if self.v is not None:
+                self.v[:, a:b].zero_()
         self.opt_steps = 0
 
     def swap_slabs(self) -> None:
@@ -448,14 +452,18 @@ class HipEngine(ShardEngine):
         """Weight gradient of a big linear layer + its optimizer update in one kernel."""
         o = self.spec.optim
         Wb, Mb = self._w(self.params, l), self._w(self.m, l)
+        # the reference builds a new optimizer every round: in its first step the moments are zero, so the
+        # kernel neither reads them nor do they have to be cleared beforehand (see reset_optimizer)
+        fresh = step_index == 1 and not self.persist_optimizer
         if o.kind == "adam":
             Vb = self._w(self.v, l)
             self.hip.linear_wgrad_adam(dy, xin, Wb[0], Mb[0], Vb[0], Wb[1], Mb[1], Vb[1], lr=o.lr, beta1=o.beta1,
                                        beta2=o.beta2, eps=o.eps, weight_decay=o.weight_decay, t=step_index,
-                                       bc=self._bc_buf[step_index - 1] if self._bc_buf is not None else None)
+                                       bc=self._bc_buf[step_index - 1] if self._bc_buf is not None else None,
+                                       fresh=fresh)
         else:
             self.hip.linear_wgrad_sgdm(dy, xin, Wb[0], Mb[0], Wb[1], Mb[1], lr=o.lr, momentum=o.momentum,
-                                       weight_decay=o.weight_decay)
+                                       weight_decay=o.weight_decay, fresh=fresh)
 
     def _optim_step(self, step_index: int) -> None:
         o = self.spec.optim
@@ -646,7 +654,7 @@ class HipEngine(ShardEngine):
             inactive = (~torch.as_tensor(active, dtype=torch.bool)).nonzero().flatten().to(self.device)
             saved = (inactive, self.params[inactive].clone())
         if self.use_graph:
-            key = (epochs, steps, n)
+            key = (epochs, steps, n, self.persist_optimizer)
             if key not in self._graphs:
                 # warm-up on a side stream (lazy module loads, allocator), then capture
                 # (a fresh stream per capture: with one long-lived warm-up stream the parallel branch of the

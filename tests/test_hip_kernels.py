@@ -111,6 +111,32 @@ def test_linear_wgrad_adam_matches_unfused(K, B, In, Out):
         assert torch.allclose(a, r, atol=1e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize("kind", ["adam", "sgd"])
+def test_fused_update_fresh_step_ignores_stale_moments(kind):
+    """fresh=True (first step of a new optimizer) on garbage moments == the ordinary step on zeroed ones."""
+    h = hip()
+    K, B, In, Out = 2, 32, 260, 70
+    n = In * Out
+    P = n + 64 - n % 64 + 512
+    view = lambda s: (s[:, :n].unflatten(1, (Out, In)), s[:, P - 512:P - 512 + Out])
+    dy = torch.randn(K, B, Out, device=DEV)
+    x = torch.randn(K, B, In, device=DEV)
+    res = []
+    for fresh in (False, True):
+        torch.manual_seed(3)
+        w = torch.randn(K, P, device=DEV) * 0.05
+        m = torch.zeros(K, P, device=DEV) if not fresh else torch.full((K, P), float("nan"), device=DEV)
+        v = m.clone()
+        (ww, wb), (mw, mb), (vw, vb) = view(w), view(m), view(v)
+        if kind == "adam":
+            h.linear_wgrad_adam(dy, x, ww, mw, vw, wb, mb, vb, lr=1e-3, t=1, fresh=fresh)
+        else:
+            h.linear_wgrad_sgdm(dy, x, ww, mw, wb, mb, lr=1e-2, momentum=0.9, fresh=fresh)
+        res.append([t.clone() for t in (ww, wb, mw, mb)] + ([vw.clone(), vb.clone()] if kind == "adam" else []))
+    for a, b in zip(*res):
+        assert torch.isfinite(b).all() and torch.equal(a, b)
+
+
 @pytest.mark.parametrize("K,B,In,Out", [(2, 32, 3136, 62), (3, 20, 130, 70), (2, 32, 256, 128)])
 def test_linear_wgrad_sgdm_matches_unfused(K, B, In, Out):
     """Fused weight gradient + SGD-momentum (with weight decay) == wgrad kernel followed by sgdm_step."""

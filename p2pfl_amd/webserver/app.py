@@ -27,7 +27,7 @@ from flask import (Flask, abort, jsonify, redirect, render_template, request, se
                    url_for)
 
 from p2pfl_amd.controller import Controller  # noqa: E402
-from p2pfl_amd.role import Role, default_roles  # noqa: E402
+from p2pfl_amd.role import default_roles  # noqa: E402
 from p2pfl_amd.utils.topologymanager import TopologyManager  # noqa: E402
 from p2pfl_amd.webserver import config as webconfig  # noqa: E402
 from p2pfl_amd.webserver import database as db  # noqa: E402

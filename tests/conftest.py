@@ -35,7 +35,6 @@ def _stream_watchdog(request):
         yield
         return
     import threading
-    import time
 
     import torch
 

@@ -1,6 +1,5 @@
 """Config, topology, roles, observer, heartbeater (fake clock), gossiper budget, codec, aggregator."""
 import pickle
-import threading
 import time
 from collections import OrderedDict
 

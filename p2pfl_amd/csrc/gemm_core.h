@@ -186,16 +186,18 @@ __device__ __forceinline__ void gemm_block_tile(GemmSmem<BM, BN, NBUF, BK>& sm, 
 struct LoadRowMajorK {
     static constexpr bool ROW_CONTIG = false;
     const float* src; int rows, kdim, ld; bool vec;
+    const int* idx = nullptr;      // optional gather: logical row r is src row idx[r] (mini-batch index list)
     __device__ __forceinline__ void load8(int row, int k, float (&v)[8]) const {
+        const int srow = (idx != nullptr && row < rows) ? idx[row] : row;
         if (vec && row < rows && k + 8 <= kdim) {
-            const float4* p = reinterpret_cast<const float4*>(src + (size_t)row * ld + k);
+            const float4* p = reinterpret_cast<const float4*>(src + (size_t)srow * ld + k);
             float4 a = p[0], b = p[1];
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
             v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                v[j] = (row < rows && k + j < kdim) ? src[(size_t)row * ld + k + j] : 0.f;
+                v[j] = (row < rows && k + j < kdim) ? src[(size_t)srow * ld + k + j] : 0.f;
         }
     }
 };

@@ -15,6 +15,7 @@ struct LinearArgs {
     const float* b;  long b_cs;   // [K][Out]     bias
     float* y;        long y_cs;   // [K][B][Out]
     int B, In, Out, relu, vec;
+    const int* sidx; long s_cs;   // optional [K][B] row indices into x (x is then the whole [K][n][In] data set)
 };
 
 struct EpiBiasAct {
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(LinearArgs a) {
     const int c = blockIdx.z;
     const float* x = a.x + c * a.x_cs;
     const float* w = a.w + c * a.w_cs;
-    LoadRowMajorK al{x, a.B, a.In, a.In, (bool)(a.vec & 1)};
+    LoadRowMajorK al{x, a.B, a.In, a.In, (bool)(a.vec & 1), a.sidx ? a.sidx + c * a.s_cs : nullptr};
     LoadRowMajorK bl{w, a.Out, a.In, a.In, (bool)(a.vec & 2)};
     EpiBiasAct epi{a.y + c * a.y_cs, a.b + c * a.b_cs, a.B, a.Out, a.relu};
     gemm_block_tile<32, 128, 1, 4, LoadRowMajorK, LoadRowMajorK, EpiBiasAct, false, NBUF, BK>(
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(1024) void linear_fwd_skinny_kernel(LinearArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, kq = (lane >> 5) * 8;
-    LoadRowMajorK xl{a.x + c * a.x_cs, a.B, a.In, a.In, (bool)(a.vec & 1)};
+    LoadRowMajorK xl{a.x + c * a.x_cs, a.B, a.In, a.In, (bool)(a.vec & 1), a.sidx ? a.sidx + c * a.s_cs : nullptr};
     LoadRowMajorK wl{a.w + c * a.w_cs, a.Out, a.In, a.In, (bool)(a.vec & 2)};
     f32x16 acc[NT];
 #pragma unroll
@@ -151,6 +152,7 @@ struct WgradArgs {
     float* dw;       long dw_cs;  // [K][Out][In]  (grad slab view)
     float* db;       long db_cs;  // [K][Out]
     int B, In, Out;
+    const int* sidx; long s_cs;
 };
 
 // x^T with one extra all-ones row at index In: the bias gradient drops out of the same
@@ -158,12 +160,13 @@ struct WgradArgs {
 struct LoadXTOnes {
     static constexpr bool ROW_CONTIG = true;
     const float* x; int In, B;
+    const int* idx = nullptr;      // optional gather of the batch rows
     __device__ __forceinline__ void load8(int row, int k, float (&v)[8]) const {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float t = 0.f;
             if (k + j < B) {
-                if (row < In) t = x[(size_t)(k + j) * In + row];
+                if (row < In) t = x[(size_t)(idx ? idx[k + j] : k + j) * In + row];
                 else if (row == In) t = 1.f;
             }
             v[j] = t;
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(WgradArgs a) {
     __shared__ GemmSmem<128, 128> sm;
     const int c = blockIdx.z;
     LoadColMajorK al{a.dy + c * a.dy_cs, a.Out, a.B, a.Out};
-    LoadXTOnes bl{a.x + c * a.x_cs, a.In, a.B};
+    LoadXTOnes bl{a.x + c * a.x_cs, a.In, a.B, a.sidx ? a.sidx + c * a.s_cs : nullptr};
     EpiWgradStore epi{a.dw + c * a.dw_cs, a.db + c * a.db_cs, a.Out, a.In};
     gemm_block_tile<128, 128, 4, 1, LoadColMajorK, LoadXTOnes, EpiWgradStore, true>(
         sm, al, bl, epi, blockIdx.y * 128, blockIdx.x * 128, 0, a.B);
@@ -279,6 +282,7 @@ struct WgradAdamArgs {
     float* b; float* mb; float* vb; long b_cs;
     int B, In, Out;
     AdamHyper h;
+    const int* sidx; long s_cs;
 };
 
 // WR x WC waves: block tile (32 WR) x (128 WC). Wider tiles (WC = 4: 32 x 512) turn the weight/moment
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_adam_kernel(WgradAdamArgs
     __shared__ GemmSmem<BM, BN, 1> sm;
     const int c = blockIdx.z;
     LoadColMajorK al{a.dy + c * a.dy_cs, a.Out, a.B, a.Out};
-    LoadXTOnes bl{a.x + c * a.x_cs, a.In, a.B};
+    LoadXTOnes bl{a.x + c * a.x_cs, a.In, a.B, a.sidx ? a.sidx + c * a.s_cs : nullptr};
     const float ib1 = a.h.bc ? a.h.bc[0] : a.h.inv_bc1;
     const float isb2 = a.h.bc ? a.h.bc[1] : a.h.inv_sqrt_bc2;
     const long wo = c * a.w_cs, bo = c * a.b_cs;
@@ -348,13 +352,14 @@ struct WgradSgdmArgs {
     int B, In, Out;
     float lr, momentum, weight_decay;
     int fresh;
+    const int* sidx; long s_cs;
 };
 
 __global__ __launch_bounds__(256, 2) void linear_wgrad_sgdm_kernel(WgradSgdmArgs a) {
     __shared__ GemmSmem<128, 128, 1> sm;
     const int c = blockIdx.z;
     LoadColMajorK al{a.dy + c * a.dy_cs, a.Out, a.B, a.Out};
-    LoadXTOnes bl{a.x + c * a.x_cs, a.In, a.B};
+    LoadXTOnes bl{a.x + c * a.x_cs, a.In, a.B, a.sidx ? a.sidx + c * a.s_cs : nullptr};
     const long wo = c * a.w_cs, bo = c * a.b_cs;
     EpiWgradSgdm epi{a.w + wo, a.mw + wo, a.b + bo, a.mb + bo, a.Out, a.In, a.lr, a.momentum, a.weight_decay,
                      a.fresh != 0};
@@ -381,12 +386,12 @@ P2PFL_API int p2pfl_linear_wgrad_adam(const float* dy, long dy_cs, const float* 
                                       float* mw, float* vw, long w_cs, float* b, float* mb, float* vb,
                                       long b_cs, int K, int B, int In, int Out, float lr, float beta1,
                                       float beta2, float eps, float weight_decay, int t, const float* bc,
-                                      int fresh, hipStream_t stream) {
+                                      int fresh, const int* sidx, long s_cs, hipStream_t stream) {
     if (K <= 0 || B <= 0 || In <= 0 || Out <= 0 || t <= 0) return -1;
     const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
     WgradAdamArgs a{dy, dy_cs, x, x_cs, w, mw, vw, w_cs, b, mb, vb, b_cs, B, In, Out,
                     AdamHyper{lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
-                              (float)(1.0 / sqrt(bc2)), bc, fresh}};
+                              (float)(1.0 / sqrt(bc2)), bc, fresh}, sidx, s_cs};
     // 128 x 128 tiles, 2 workgroups per CU: measured best of {128x128, 64x256, 32x512} x {2, 3, 4 per CU}
     // (2.87 / 2.90 / 3.31 ms and 2.87 / 2.99 / 4.09 ms for 100 clients x 3136x2048 on MI355X)
     const dim3 grid(cdiv(In + 1, 128), cdiv(Out, 128), K);
@@ -397,9 +402,10 @@ P2PFL_API int p2pfl_linear_wgrad_adam(const float* dy, long dy_cs, const float* 
 P2PFL_API int p2pfl_linear_wgrad_sgdm(const float* dy, long dy_cs, const float* x, long x_cs, float* w,
                                       float* mw, long w_cs, float* b, float* mb, long b_cs, int K, int B,
                                       int In, int Out, float lr, float momentum, float weight_decay,
-                                      int fresh, hipStream_t stream) {
+                                      int fresh, const int* sidx, long s_cs, hipStream_t stream) {
     if (K <= 0 || B <= 0 || In <= 0 || Out <= 0) return -1;
-    WgradSgdmArgs a{dy, dy_cs, x, x_cs, w, mw, w_cs, b, mb, b_cs, B, In, Out, lr, momentum, weight_decay, fresh};
+    WgradSgdmArgs a{dy, dy_cs, x, x_cs, w, mw, w_cs, b, mb, b_cs, B, In, Out, lr, momentum, weight_decay, fresh,
+                    sidx, s_cs};
     const dim3 grid(cdiv(In + 1, 128), cdiv(Out, 128), K);
     hipLaunchKernelGGL(linear_wgrad_sgdm_kernel, grid, dim3(256), 0, stream, a);
     P2PFL_RETURN_LAST_ERROR();
@@ -407,12 +413,12 @@ P2PFL_API int p2pfl_linear_wgrad_sgdm(const float* dy, long dy_cs, const float* 
 
 P2PFL_API int p2pfl_linear_fwd(const float* x, long x_cs, const float* w, long w_cs, const float* b,
                                long b_cs, float* y, long y_cs, int K, int B, int In, int Out,
-                               int relu, hipStream_t stream) {
+                               int relu, const int* sidx, long s_cs, hipStream_t stream) {
     if (K <= 0 || B <= 0 || In <= 0 || Out <= 0) return -1;
     // float4 loads need In % 4 == 0 and 16-B aligned bases/strides; otherwise element loads
     const int xv = !((In & 3) || (x_cs & 3) || ((uintptr_t)x & 15));
     const int wv = !((In & 3) || (w_cs & 3) || ((uintptr_t)w & 15));
-    LinearArgs a{x, x_cs, w, w_cs, b, b_cs, y, y_cs, B, In, Out, relu, xv | (wv << 1)};
+    LinearArgs a{x, x_cs, w, w_cs, b, b_cs, y, y_cs, B, In, Out, relu, xv | (wv << 1), sidx, s_cs};
     // (with >= 2 tiles per CU the tiled kernel hides the latency itself: 1000 clients x 3136 -> 62: 259 vs 300 us)
     if (Out <= 64 && In >= 512 && (long)K * cdiv(B, 32) <= 2L * num_cus()) {
         const dim3 sgrid(1, cdiv(B, 32), K);
@@ -448,9 +454,9 @@ P2PFL_API int p2pfl_linear_dgrad(const float* dy, long dy_cs, const float* w, lo
 
 P2PFL_API int p2pfl_linear_wgrad(const float* dy, long dy_cs, const float* x, long x_cs, float* dw,
                                  long dw_cs, float* db, long db_cs, int K, int B, int In, int Out,
-                                 hipStream_t stream) {
+                                 const int* sidx, long s_cs, hipStream_t stream) {
     if (K <= 0 || B <= 0 || In <= 0 || Out <= 0) return -1;
-    WgradArgs a{dy, dy_cs, x, x_cs, dw, dw_cs, db, db_cs, B, In, Out};
+    WgradArgs a{dy, dy_cs, x, x_cs, dw, dw_cs, db, db_cs, B, In, Out, sidx, s_cs};
     dim3 grid(cdiv(In + 1, 128), cdiv(Out, 128), K);
     hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(256), 0, stream, a);
     P2PFL_RETURN_LAST_ERROR();

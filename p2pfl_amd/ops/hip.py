@@ -50,11 +50,11 @@ P, L, I, F = c_void_p, c_long, c_int, c_float
 
 
 class _Sig:
-    p2pfl_linear_fwd = [P, L, P, L, P, L, P, L, I, I, I, I, I, P]
+    p2pfl_linear_fwd = [P, L, P, L, P, L, P, L, I, I, I, I, I, P, L, P]
     p2pfl_linear_dgrad = [P, L, P, L, P, L, P, L, I, I, I, I, P]
-    p2pfl_linear_wgrad = [P, L, P, L, P, L, P, L, I, I, I, I, P]
-    p2pfl_linear_wgrad_adam = [P, L, P, L, P, P, P, L, P, P, P, L, I, I, I, I, F, F, F, F, F, I, P, I, P]
-    p2pfl_linear_wgrad_sgdm = [P, L, P, L, P, P, L, P, P, L, I, I, I, I, F, F, F, I, P]
+    p2pfl_linear_wgrad = [P, L, P, L, P, L, P, L, I, I, I, I, P, L, P]
+    p2pfl_linear_wgrad_adam = [P, L, P, L, P, P, P, L, P, P, P, L, I, I, I, I, F, F, F, F, F, I, P, I, P, L, P]
+    p2pfl_linear_wgrad_sgdm = [P, L, P, L, P, P, L, P, P, L, I, I, I, I, F, F, F, I, P, L, P]
     p2pfl_conv1_fwd = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, P]
     p2pfl_conv1_wgrad = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, P]
     p2pfl_conv2_prep = [P, L, P, L, I, I, I, I, P]
@@ -102,13 +102,17 @@ def _pc(t: Optional[torch.Tensor], dtype=torch.float32):
 
 
 # ----------------------------------------------------------------------------- linear
-def linear_fwd(x, w, b, y, relu: bool) -> None:
-    """y[k] = act(x[k] @ w[k].T + b[k]);  x [K,B,In], w [K,Out,In], b [K,Out], y [K,B,Out]."""
-    K, B, In = x.shape
-    Out = w.shape[1]
-    assert w.shape == (K, Out, In) and b.shape == (K, Out) and y.shape == (K, B, Out)
-    (xp, xs), (wp, ws), (bp, bs), (yp, ys) = _pc(x), _pc(w), _pc(b), _pc(y)
-    _chk(load().p2pfl_linear_fwd(xp, xs, wp, ws, bp, bs, yp, ys, K, B, In, Out, int(relu), _stream()),
+def linear_fwd(x, w, b, y, relu: bool, sidx=None) -> None:
+    """y[k] = act(x[k] @ w[k].T + b[k]);  x [K,B,In], w [K,Out,In], b [K,Out], y [K,B,Out].
+
+    ``sidx`` [K,B] int32: x is the whole data set [K,n,In] and row r of the product is x[k, sidx[k, r]] (the
+    mini-batch gather of a first dense layer happens in the operand loader)."""
+    K, B, Out = y.shape
+    In = x.shape[2]
+    assert w.shape == (K, Out, In) and b.shape == (K, Out) and (sidx is not None or x.shape[1] == B)
+    (xp, xs), (wp, ws), (bp, bs), (yp, ys), (sp, ss) = _pc(x), _pc(w), _pc(b), _pc(y), _pc(sidx, torch.int32)
+    assert sidx is None or sidx.shape == (K, B)
+    _chk(load().p2pfl_linear_fwd(xp, xs, wp, ws, bp, bs, yp, ys, K, B, In, Out, int(relu), sp, ss, _stream()),
          "linear_fwd")
 
 
@@ -121,17 +125,18 @@ def linear_dgrad(dy, w, act, dx) -> None:
     _chk(load().p2pfl_linear_dgrad(dp, ds, wp, ws, ap, as_, xp, xs, K, B, In, Out, _stream()), "linear_dgrad")
 
 
-def linear_wgrad(dy, x, dw, db) -> None:
-    """dw[k] = dy[k].T @ x[k];  db[k] = dy[k].sum(0)."""
+def linear_wgrad(dy, x, dw, db, sidx=None) -> None:
+    """dw[k] = dy[k].T @ x[k];  db[k] = dy[k].sum(0).   (``sidx``: batch rows gathered from x, see linear_fwd)"""
     K, B, Out = dy.shape
     In = x.shape[2]
-    assert dw.shape == (K, Out, In) and db.shape == (K, Out)
-    (dp, ds), (xp, xs), (wp, ws), (bp, bs) = _pc(dy), _pc(x), _pc(dw), _pc(db)
-    _chk(load().p2pfl_linear_wgrad(dp, ds, xp, xs, wp, ws, bp, bs, K, B, In, Out, _stream()), "linear_wgrad")
+    assert dw.shape == (K, Out, In) and db.shape == (K, Out) and (sidx is None or sidx.shape == (K, B))
+    (dp, ds), (xp, xs), (wp, ws), (bp, bs), (sp, ss) = _pc(dy), _pc(x), _pc(dw), _pc(db), _pc(sidx, torch.int32)
+    _chk(load().p2pfl_linear_wgrad(dp, ds, xp, xs, wp, ws, bp, bs, K, B, In, Out, sp, ss, _stream()),
+         "linear_wgrad")
 
 
 def linear_wgrad_adam(dy, x, w, mw, vw, b, mb, vb, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
-                      t: int, bc=None, fresh: bool = False) -> None:
+                      t: int, bc=None, fresh: bool = False, sidx=None) -> None:
     """Fused ``dw = dy.T @ x`` + Adam update of (w, b) and their moments; the gradient is never
     written to memory. w/mw/vw are [K,Out,In] slab views with one common row stride, b/mb/vb [K,Out].
     ``fresh``: first step of a new optimizer - the moments count as zero and are not read (only written)."""
@@ -139,25 +144,26 @@ def linear_wgrad_adam(dy, x, w, mw, vw, b, mb, vb, *, lr, beta1=0.9, beta2=0.999
     In = x.shape[2]
     assert w.shape == (K, Out, In) and b.shape == (K, Out)
     assert w.stride(0) == mw.stride(0) == vw.stride(0) and b.stride(0) == mb.stride(0) == vb.stride(0)
-    (dp, ds), (xp, xs) = _pc(dy), _pc(x)
+    (dp, ds), (xp, xs), (sp, ss) = _pc(dy), _pc(x), _pc(sidx, torch.int32)
     _chk(load().p2pfl_linear_wgrad_adam(dp, ds, xp, xs, _t(w).data_ptr(), _t(mw).data_ptr(), _t(vw).data_ptr(),
                                         w.stride(0), _t(b).data_ptr(), _t(mb).data_ptr(), _t(vb).data_ptr(),
                                         b.stride(0), K, B, In, Out, lr, beta1, beta2, eps, weight_decay, t,
-                                        None if bc is None else _t(bc).data_ptr(), int(fresh), _stream()),
+                                        None if bc is None else _t(bc).data_ptr(), int(fresh), sp, ss, _stream()),
          "linear_wgrad_adam")
 
 
-def linear_wgrad_sgdm(dy, x, w, mw, b, mb, *, lr, momentum=0.9, weight_decay=0.0, fresh: bool = False) -> None:
+def linear_wgrad_sgdm(dy, x, w, mw, b, mb, *, lr, momentum=0.9, weight_decay=0.0, fresh: bool = False,
+                      sidx=None) -> None:
     """Fused ``dw = dy.T @ x`` + SGD-momentum update of (w, b) and their momentum buffers (same layout rules
     as :func:`linear_wgrad_adam`)."""
     K, B, Out = dy.shape
     In = x.shape[2]
     assert w.shape == (K, Out, In) and b.shape == (K, Out)
     assert w.stride(0) == mw.stride(0) and b.stride(0) == mb.stride(0)
-    (dp, ds), (xp, xs) = _pc(dy), _pc(x)
+    (dp, ds), (xp, xs), (sp, ss) = _pc(dy), _pc(x), _pc(sidx, torch.int32)
     _chk(load().p2pfl_linear_wgrad_sgdm(dp, ds, xp, xs, _t(w).data_ptr(), _t(mw).data_ptr(), w.stride(0),
                                         _t(b).data_ptr(), _t(mb).data_ptr(), b.stride(0), K, B, In, Out, lr,
-                                        momentum, weight_decay, int(fresh), _stream()), "linear_wgrad_sgdm")
+                                        momentum, weight_decay, int(fresh), sp, ss, _stream()), "linear_wgrad_sgdm")
 
 
 # ----------------------------------------------------------------------------- conv

@@ -282,7 +282,6 @@ class HipEngine(ShardEngine):
         # tap-major bf16 weight copies of the stage-2 convolutions (refreshed at every forward pass)
         self.wprep = {i: hip.conv2_prep_alloc(K, l.ksize, dev) for i, l in enumerate(self.spec.layers)
                       if l.kind == "conv2pool"}
-        self.xin = self._alloc_xin(B)
         self.karange = torch.arange(K, device=dev).unsqueeze(1)
         self._nv_cache: Dict[int, torch.Tensor] = {}
         self._tail_cache: Dict[tuple, torch.Tensor] = {}
@@ -293,9 +292,13 @@ class HipEngine(ShardEngine):
             cut = []
             for i, l in enumerate(self.spec.layers):
                 ws, bs = L.by_name[l.weight], L.by_name[l.bias]
-                # per client >= 1 M weights, or a shard of them that no longer fits the 256 MB infinity cache
-                # (50 FEMNIST clients x 0.19 M: the fused kernel is 22 us per step SLOWER than wgrad + SGD)
-                big = ws.numel >= (1 << 20) or (ws.numel >= (1 << 16) and K * ws.numel >= (1 << 26))
+                # per client >= 1 M weights, or a shard of them that no longer fits the 256 MB infinity cache -
+                # or the L2s, when the layer fills whole 128-row tiles. (100 MLP clients, 784 -> 256: 17.7 ->
+                # 16.4 ms per round fused; 50 FEMNIST clients, 3136 -> 62, i.e. half-empty tiles: the fused
+                # kernel is 22 us per step SLOWER than wgrad + SGD.)
+                shard = K * ws.numel
+                big = ws.numel >= (1 << 20) or (ws.numel >= (1 << 16) and (
+                    shard >= (1 << 26) or (shard >= (1 << 24) and l.out_features % 128 == 0)))
                 if l.kind == "linear" and big and bs.offset == ws.offset + -(-ws.numel // 64) * 64:
                     self._fused.add(i)
                     cut.append((ws.offset, bs.offset + -(-bs.numel // 64) * 64))
@@ -352,19 +355,16 @@ class HipEngine(ShardEngine):
             code.append(torch.zeros(shp, dtype=torch.uint8, device=self.device) if l.kind != "linear" else None)
         return act, code
 
-    def _alloc_xin(self, B: int):
-        return torch.zeros(self.K, B, 784, device=self.device) if self.spec.layers[0].kind == "linear" else None
-
     def _eval_batch(self, n: int) -> int:
         """Rows per evaluation pass over a split of n samples: a multiple of 32, at least the training batch."""
         return max(self.B, min(self.EVAL_B, -(-n // 32) * 32))
 
     def _bufs(self, B: int):
-        """(act, code, xin, B) for batch size B (the training buffers, or lazily made evaluation ones)."""
+        """(act, code, B) for batch size B (the training buffers, or lazily made evaluation ones)."""
         if B == self.B:
-            return self.act, self.code, self.xin, B
+            return self.act, self.code, B
         if B not in self._eval_bufs:
-            self._eval_bufs[B] = self._alloc_acts(B) + (self._alloc_xin(B), B)
+            self._eval_bufs[B] = self._alloc_acts(B) + (B,)
         return self._eval_bufs[B]
 
     # ------------------------------------------------------------------ helpers
@@ -392,7 +392,7 @@ class HipEngine(ShardEngine):
     # ------------------------------------------------------------------ one batch
     def _forward(self, data, sidx, labels, n_valid, phase: str, train: bool, bufs=None, prep: bool = True) -> None:
         hip, layers = self.hip, self.spec.layers
-        act, code, xin, B = bufs if bufs is not None else (self.act, self.code, self.xin, self.B)
+        act, code, B = bufs if bufs is not None else (self.act, self.code, self.B)
         x = None
         for i, l in enumerate(layers):
             W, b = self._w(self.params, l)
@@ -403,13 +403,10 @@ class HipEngine(ShardEngine):
                     hip.conv2_prep(W, self.wprep[i], l.ksize)
                 hip.conv2_fwd(x, W, b, act[i], code[i], l.ksize, wprep=self.wprep[i])
             else:
-                if x is None:
-                    if sidx is None:
-                        x = data[:, :B]
-                    else:
-                        xin.copy_(data[self.karange, sidx.long()])
-                        x = xin
-                hip.linear_fwd(x.flatten(2) if x.dim() > 3 else x, W, b, act[i], l.relu)
+                if x is None:      # first layer: the mini-batch rows are gathered by the kernel's operand loader
+                    hip.linear_fwd(data if sidx is not None else data[:, :B], W, b, act[i], l.relu, sidx=sidx)
+                else:
+                    hip.linear_fwd(x.flatten(2) if x.dim() > 3 else x, W, b, act[i], l.relu)
             x = act[i]
         st = self.stats[phase]
         hip.softmax_ce(x, labels, sidx, self.dact[-1] if train else None, st.loss_sum, st.correct, st.count,
@@ -424,8 +421,9 @@ class HipEngine(ShardEngine):
             W, _ = self._w(self.params, l)
             gW, gb = self._w(self.grads, l)
             if l.kind == "linear":
+                gather = None
                 if i == 0:
-                    xin = self.xin if sidx is not None else data[:, :self.B]
+                    xin, gather = (data, sidx) if sidx is not None else (data[:, :self.B], None)
                 else:
                     xin = self.act[i - 1].flatten(2) if self.act[i - 1].dim() > 3 else self.act[i - 1]
                 dy_next = None
@@ -436,9 +434,9 @@ class HipEngine(ShardEngine):
                     hip.linear_dgrad(dy, W, mask, dx)
                     dy_next = self.dact[i - 1]
                 if i in self._fused:
-                    self._fused_update(l, dy, xin, step_index)
+                    self._fused_update(l, dy, xin, step_index, sidx=gather)
                 else:
-                    hip.linear_wgrad(dy, xin, gW, gb)
+                    hip.linear_wgrad(dy, xin, gW, gb, sidx=gather)
                 if dy_next is not None:
                     dy = dy_next
             elif l.kind == "conv2pool":
@@ -448,7 +446,7 @@ class HipEngine(ShardEngine):
             else:  # conv1pool (first layer: no data gradient)
                 hip.conv1_wgrad(dy, self.code[i], data, sidx, gW, gb, l.ksize)
 
-    def _fused_update(self, l, dy, xin, step_index: int) -> None:
+    def _fused_update(self, l, dy, xin, step_index: int, sidx=None) -> None:
         """Weight gradient of a big linear layer + its optimizer update in one kernel."""
         o = self.spec.optim
         Wb, Mb = self._w(self.params, l), self._w(self.m, l)
@@ -460,10 +458,10 @@ class HipEngine(ShardEngine):
             self.hip.linear_wgrad_adam(dy, xin, Wb[0], Mb[0], Vb[0], Wb[1], Mb[1], Vb[1], lr=o.lr, beta1=o.beta1,
                                        beta2=o.beta2, eps=o.eps, weight_decay=o.weight_decay, t=step_index,
                                        bc=self._bc_buf[step_index - 1] if self._bc_buf is not None else None,
-                                       fresh=fresh)
+                                       fresh=fresh, sidx=sidx)
         else:
             self.hip.linear_wgrad_sgdm(dy, xin, Wb[0], Mb[0], Wb[1], Mb[1], lr=o.lr, momentum=o.momentum,
-                                       weight_decay=o.weight_decay, fresh=fresh)
+                                       weight_decay=o.weight_decay, fresh=fresh, sidx=sidx)
 
     def _optim_step(self, step_index: int) -> None:
         o = self.spec.optim

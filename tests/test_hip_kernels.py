@@ -111,6 +111,37 @@ def test_linear_wgrad_adam_matches_unfused(K, B, In, Out):
         assert torch.allclose(a, r, atol=1e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize("K,B,n,In,Out", [(3, 32, 100, 784, 256), (2, 20, 57, 130, 10), (2, 32, 64, 2048, 10)])
+def test_linear_gather_of_batch_rows(K, B, n, In, Out):
+    """sidx: forward / weight gradient / fused update read the mini-batch rows straight from the data set."""
+    h = hip()
+    data = torch.randn(K, n, In, device=DEV)
+    sidx = torch.stack([torch.randperm(n, device=DEV)[:B] for _ in range(K)]).int()
+    xb = data[torch.arange(K, device=DEV)[:, None], sidx.long()].contiguous()
+    w = slab_view(K, (Out, In)) * 0.05
+    b = slab_view(K, (Out,)) * 0.1
+    y1, y2 = torch.empty(K, B, Out, device=DEV), torch.empty(K, B, Out, device=DEV)
+    h.linear_fwd(data, w, b, y1, True, sidx=sidx)
+    h.linear_fwd(xb, w, b, y2, True)
+    assert torch.equal(y1, y2)
+    dy = torch.randn(K, B, Out, device=DEV)
+    g1, g2 = (slab_view(K, (Out, In)), slab_view(K, (Out,))), (slab_view(K, (Out, In)), slab_view(K, (Out,)))
+    h.linear_wgrad(dy, data, g1[0], g1[1], sidx=sidx)
+    h.linear_wgrad(dy, xb, g2[0], g2[1])
+    assert torch.equal(g1[0], g2[0]) and torch.equal(g1[1], g2[1])
+    P = In * Out + 64 - (In * Out) % 64 + 512
+    view = lambda s: (s[:, :In * Out].unflatten(1, (Out, In)), s[:, P - 512:P - 512 + Out])
+    res = []
+    for gather in (True, False):
+        torch.manual_seed(1)
+        slabs = [torch.randn(K, P, device=DEV) * 0.05, torch.zeros(K, P, device=DEV), torch.zeros(K, P, device=DEV)]
+        (ww, wb), (mw, mb), (vw, vb) = view(slabs[0]), view(slabs[1]), view(slabs[2])
+        h.linear_wgrad_adam(dy, data if gather else xb, ww, mw, vw, wb, mb, vb, lr=1e-3, t=1,
+                            sidx=sidx if gather else None)
+        res.append(slabs[0].clone())
+    assert torch.equal(res[0], res[1])
+
+
 @pytest.mark.parametrize("kind", ["adam", "sgd"])
 def test_fused_update_fresh_step_ignores_stale_moments(kind):
     """fresh=True (first step of a new optimizer) on garbage moments == the ordinary step on zeroed ones."""

@@ -43,6 +43,7 @@ PRESETS = {
     "femnist50-ring": dict(model="femnist-cnn", nodes_per_gpu=50, split_nodes=50, topology="ring"),
     "cnn100-encrypted-churn": dict(model="mnist-cnn", nodes_per_gpu=100, split_nodes=100, topology="random",
                                    encrypt=True, churn=0.1),
+    "mlp100-random": dict(model="mnist-mlp", nodes_per_gpu=100, split_nodes=100, topology="random"),   # extra: the MLP
     "femnist1000-star": dict(model="femnist-cnn", nodes_per_gpu=1000, split_nodes=1000, topology="star",
                              federation="CFL"),
 }

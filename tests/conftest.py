@@ -27,10 +27,10 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture(autouse=True)
 def _stream_watchdog(request):
-    """P2PFL_STREAM_WATCHDOG=<seconds>: if a GPU test runs longer, report which HIP streams still hold work
-    (the engine's auxiliary streams and the default stream) and leave - a stalled device wait cannot be
-    interrupted from Python otherwise."""
-    limit = float(os.environ.get("P2PFL_STREAM_WATCHDOG", "0") or 0)
+    """If a GPU test runs longer than P2PFL_STREAM_WATCHDOG seconds (default 120, 0 = off), report which HIP
+    streams still hold work (the engines' auxiliary streams and the default stream) and leave - a stalled
+    device wait cannot be interrupted from Python otherwise."""
+    limit = float(os.environ.get("P2PFL_STREAM_WATCHDOG", "120") or 0)
     if limit <= 0 or "gpu" not in request.keywords:
         yield
         return

@@ -36,7 +36,8 @@ class _RestrictedUnpickler(pickle.Unpickler):
 
 def encode_parameters(arrays: Sequence[np.ndarray], contributors: Optional[List[str]] = None,
                       weight: Optional[int] = None) -> bytes:
-    arrays = [np.ascontiguousarray(a) for a in arrays]
+    # (np.ascontiguousarray would turn 0-d entries - BatchNorm's num_batches_tracked - into shape (1,))
+    arrays = [np.asarray(a, order="C") for a in arrays]
     return pickle.dumps((arrays, contributors, weight))
 
 

@@ -12,6 +12,7 @@ falling back to eager PyTorch.
 from __future__ import annotations
 
 import ctypes
+import threading
 from ctypes import c_float, c_int, c_long, c_void_p
 from typing import Optional
 
@@ -239,7 +240,7 @@ def conv2_wgrad(g, code, a1, dw, db, ks: int) -> None:
     need = int(lib.p2pfl_conv2_wgrad_scratch(K, B, ks))
     sp = 0
     if need:
-        key = (g.device, int(stream or 0))
+        key = (g.device, int(stream or 0), threading.get_ident())   # engines of several threads may share a stream
         buf = _wgrad_scratch.get(key)
         if buf is None or buf.numel() < need:
             buf = _wgrad_scratch[key] = torch.empty(need, dtype=torch.float32, device=g.device)

@@ -1,0 +1,60 @@
+"""The per-process node's learner on a GPU: spec models (MNIST MLP / CNN, FEMNIST CNN) train through a
+one-client HipEngine, everything else through stock PyTorch-ROCm ops on the device."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _learner(ds, model, n=200):
+    from p2pfl_amd.config.config import Config, default_participant
+    from p2pfl_amd.learning.pytorch.lightninglearner import LightningLearner
+    from p2pfl_amd.node_start import build_dataset_and_model
+    p = default_participant()
+    p["device_args"]["accelerator"] = "gpu"
+    data, m = build_dataset_and_model(ds, model, 0, n)
+    return LightningLearner(m, data, config=Config(participant=p))
+
+
+@pytest.mark.parametrize("ds,model,engine", [("MNIST", "MLP", True), ("MNIST", "CNN", True), ("FEMNIST", "CNN", True),
+                                             ("SYSCALL", "MLP", False), ("CIFAR10", "simplemobilenet", False)])
+def test_learner_trains_on_the_gpu(ds, model, engine):
+    ln = _learner(ds, model)
+    assert ln.device.type == "cuda" and ln._use_engine() == engine
+    ln.set_epochs(2)
+    ln.init()
+    before = {k: v.detach().cpu().clone() for k, v in ln.get_parameters().items()}
+    res0 = ln.evaluate()
+    ln.fit()
+    res1 = ln.evaluate()
+    after = ln.get_parameters()
+    assert any(not torch.equal(before[k], after[k].detach().cpu()) for k in before)
+    assert all(torch.isfinite(v.float()).all() for v in after.values())
+    assert res0 is not None and res1 is not None
+    if engine:
+        assert ln._engine is not None                            # the HIP engine ran ...
+        # ... and the loss went down (the synthetic 62-class FEMNIST set needs more than two epochs of SGD)
+        assert res1[0] < res0[0] + (0.05 if ds == "FEMNIST" else 0.0)
+    # the payload round-trips (host numpy arrays whatever the device)
+    sd, contributors, weight = ln.decode_parameters(ln.encode_parameters(contributors=["a:1"], weight=3))
+    assert ln.check_parameters(sd) and contributors == ["a:1"] and weight == 3
+
+
+def test_two_engine_learners_in_threads_share_the_gpu():
+    """Two in-process nodes (threads) fit at the same time on one device, like a multi-node test process."""
+    import threading
+    lns = [_learner("MNIST", "CNN"), _learner("MNIST", "CNN")]
+    for ln in lns:
+        ln.set_epochs(1)
+        ln.init()
+        ln.fit()                   # graphs captured one after the other
+    ref = [ln.evaluate()[0] for ln in lns]
+    ts = [threading.Thread(target=ln.fit) for ln in lns]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    for ln, r in zip(lns, ref):
+        loss = ln.evaluate()[0]
+        assert loss == loss and loss < r * 1.5

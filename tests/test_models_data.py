@@ -251,6 +251,18 @@ def test_learner_contract_fit_evaluate_payload():
     assert ln.evaluate() is None and all(torch.equal(before[k], v) for k, v in ln.get_parameters().items())
 
 
+def test_payload_keeps_zero_dim_entries_of_batchnorm_models():
+    """BatchNorm's ``num_batches_tracked`` is a 0-d tensor: it must come back 0-d or the receiver refuses the
+    model (check_parameters compares shapes)."""
+    ln = _learner("SYSCALL", "MLP")
+    ln.set_epochs(1)
+    ln.init()
+    ln.fit()
+    sd, _, _ = ln.decode_parameters(ln.encode_parameters(contributors=["a:1"], weight=3))
+    assert sd["batchnorm1.num_batches_tracked"].shape == () and ln.check_parameters(sd)
+    ln.set_parameters(sd)
+
+
 def test_learner_interrupt_and_non_classifier_models():
     ln = _learner()
     ln.set_epochs(50)

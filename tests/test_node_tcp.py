@@ -200,3 +200,25 @@ def test_ring_over_tcp_each_node_averages_exactly_its_train_set():
             assert torch.allclose(got - shift, base, atol=1e-6), (i, (got - shift - base).abs().max())
     finally:
         stop_all(nodes)
+
+
+def test_two_nodes_exchange_a_batchnorm_model_over_tcp():
+    """Models with BatchNorm carry 0-d integer buffers (num_batches_tracked) in their payload: both nodes must
+    accept each other's model and end the rounds with the same aggregate."""
+    from p2pfl_amd.node_start import build_dataset_and_model
+    nodes = []
+    for i in range(2):
+        data, model = build_dataset_and_model("SYSCALL", "MLP", i, 20)
+        node = Node(i, "test", model, data, config=make_config(Role.AGGREGATOR, "DFL", 2, i))
+        node.start()
+        nodes.append(node)
+    try:
+        assert nodes[0].connect_to(nodes[1].host, nodes[1].port) is not None
+        time.sleep(0.5)
+        nodes[0].set_start_learning(rounds=2, epochs=1)
+        assert wait_finished(nodes)
+        sa, sb = nodes[0].learner.get_parameters(), nodes[1].learner.get_parameters()
+        assert all(torch.allclose(sa[k].float(), sb[k].float(), atol=1e-6) for k in sa)
+        assert sa["batchnorm1.num_batches_tracked"].shape == ()
+    finally:
+        stop_all(nodes)

@@ -290,10 +290,13 @@ class Controller:
         p0 = self.config.participants[0]
         pair = (p0["data_args"]["dataset"], p0["model_args"]["model"])
         homogeneous = all((p["data_args"]["dataset"], p["model_args"]["model"]) == pair for p in self.config.participants)
-        ok = homogeneous and pair in BATCHED_PAIRS
-        if self.engine == "batched" and not ok:
-            raise ValueError(f"--engine batched needs one of {sorted(BATCHED_PAIRS)} on every node")
-        return ok
+        if self.engine == "batched":
+            # every family of the factory runs batched (kernel-level specs on the HIP engine, the others as
+            # nn.Modules on stock ops with their state in the slab) - but all nodes must run the same one
+            if not homogeneous:
+                raise ValueError("--engine batched needs the same dataset / model on every node")
+            return True
+        return homogeneous and pair in BATCHED_PAIRS      # auto: the client-batched HIP kernels
 
     def create_topology(self, matrix=None):
         import numpy as np

@@ -74,6 +74,11 @@ def build_dataset_and_model(dataset: str, model_name: str, idx: int, n_nodes: in
     raise ValueError(f"Dataset {dataset} not supported")
 
 
+def build_model(dataset: str, model_name: str):
+    """Only the model of :func:`build_dataset_and_model` (a tiny throw-away split keeps the data part cheap)."""
+    return build_dataset_and_model(dataset, model_name, 0, 1000)[1]
+
+
 def main():
     config_path = str(sys.argv[1])
     config = Config(entity="participant", participant_config_file=config_path)

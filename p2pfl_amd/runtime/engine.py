@@ -94,6 +94,13 @@ class ShardEngine:
     def set_state_dict(self, k: int, sd) -> None:
         self.layout.state_dict_to_row(sd, self.params[k])
 
+    def get_arrays(self, k: int):
+        """Payload of client k: numpy arrays in state_dict order (reference lightninglearner.py:73-89)."""
+        return self.layout.row_to_arrays(self.params[k])
+
+    def set_arrays(self, k: int, arrays) -> None:
+        self.layout.arrays_to_row(arrays, self.params[k])
+
     def alt_slab(self) -> torch.Tensor:
         if self.params_alt is None:
             self.params_alt = torch.zeros_like(self.params)
@@ -711,6 +718,11 @@ class HipEngine(ShardEngine):
 def make_engine(spec: ModelSpec, n_clients: int, device, impl: str = "auto", **kw) -> ShardEngine:
     """``impl``: "hip" | "eager" | "auto" (hip on a GPU, eager on the CPU)."""
     device = torch.device(device)
+    if not isinstance(spec, ModelSpec):     # a ModuleSpec: model family without kernel-level spec (stock ops)
+        from .module_engine import ModuleEngine
+        kw.pop("use_graph", None)
+        kw.pop("overlap", None)
+        return ModuleEngine(spec, n_clients, device, **kw)
     if impl == "auto":
         impl = "hip" if device.type == "cuda" else "eager"
     if impl == "hip":

@@ -31,7 +31,7 @@ from ..learning.codec import save_checkpoint
 from ..learning.metrics import metrics_from_confusion
 from ..learning.pytorch.statisticslogger import CSVLogger
 from ..models.specs import get_spec
-from ..node_start import build_dataset_and_model
+from ..node_start import build_dataset_and_model, build_model
 from .federation import BatchedFederation
 
 _SPEC_OF = {("MNIST", "MLP"): "mnist-mlp", ("MNIST", "CNN"): "mnist-cnn", ("FEMNIST", "CNN"): "femnist-cnn"}
@@ -92,9 +92,16 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
     p0 = parts[0]
     n = len(parts)
     key = (p0["data_args"]["dataset"], p0["model_args"]["model"])
-    if key not in _SPEC_OF:
-        raise ValueError(f"the batched engine runs {sorted(_SPEC_OF)}; {key} needs the per-process node_start path")
-    spec = get_spec(_SPEC_OF[key])
+    root_dir = p0["data_args"].get("root_dir")
+    if key in _SPEC_OF:
+        spec = get_spec(_SPEC_OF[key])               # client-batched HIP kernels
+    else:
+        # every other family of the reference's factory: its nn.Module on stock PyTorch-ROCm ops, state in the
+        # same [K, P] slab (runtime/module_engine.py). Raises ValueError for unknown dataset / model names.
+        from .module_engine import ModuleSpec
+        probe = build_dataset_and_model(key[0], key[1], 0, n, root_dir)[0]
+        spec = ModuleSpec(f"{key[0]}-{key[1]}", lambda: build_model(key[0], key[1]), int(probe.num_classes),
+                          tuple(probe.input_shape))
     scenario = p0["scenario_args"]["name"] or os.path.basename(os.path.normpath(config_dir))
     federation = p0["scenario_args"]["federation"]
     roles = [p["device_args"]["role"] for p in parts]
@@ -109,8 +116,14 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
     for f in load_faults(config_dir, parts):
         fed.schedule_fault(int(f["round"]), f["action"], int(f["node"]), f.get("peer"))
     # data shards of the local nodes (real files when present, synthetic otherwise)
-    shards = [build_dataset_and_model(key[0], key[1], i, n, p0["data_args"].get("root_dir"))[0] for i in fed.local]
-    stack = lambda idx: None if shards[0].tensors()[idx] is None else torch.stack([s.tensors()[idx] for s in shards])
+    shards = [build_dataset_and_model(key[0], key[1], i, n, root_dir)[0] for i in fed.local]
+
+    def stack(idx):
+        ts = [s.tensors()[idx] for s in shards]
+        if ts[0] is None:
+            return None
+        m = min(len(t) for t in ts)                  # (splits can differ by a row between nodes)
+        return torch.stack([t[:m] for t in ts])
     fed.init_params()
     fed.set_local_data(*(stack(i) for i in range(6)))
     first_round = 0
@@ -119,7 +132,7 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
         from ..learning.codec import load_checkpoint
         for k, i in enumerate(fed.local):
             arrays, _, _, meta = load_checkpoint(os.path.join(resume, f"participant_{i}_final.ckpt"))
-            fed.engine.layout.arrays_to_row(arrays, fed.engine.params[k])
+            fed.engine.set_arrays(k, arrays)
             first_round = max(first_round, int((meta or {}).get("round", 0)))
 
     log_root = os.path.join(p0["tracking_args"].get("log_dir") or "logs", scenario)
@@ -170,7 +183,7 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
     if save_models:
         for k, i in enumerate(fed.local):
             save_checkpoint(os.path.join(log_root, f"participant_{i}_final.ckpt"),
-                            fed.engine.layout.row_to_arrays(fed.engine.params[k]),
+                            fed.engine.get_arrays(k),
                             [f"{parts[i]['network_args']['ip']}:{parts[i]['network_args']['port']}"],
                             int(fed.weights[i]), meta={"round": first_round + rounds, "role": fed.roles[i]})
     for f in node_logs.values():

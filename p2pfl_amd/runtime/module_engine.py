@@ -1,0 +1,204 @@
+"""Batched engine for ARBITRARY model families (BatchNorm / dropout / depthwise / residual / auto-encoders / SVMs).
+
+The spec models (MNIST MLP / CNN, FEMNIST CNN) train through the hand-written client-batched HIP kernels
+(:class:`HipEngine`). Every other family of the reference's factory (node_start.py:48-85: CIFAR-10 ResNets and
+MobileNets, SYSCALL MLP / auto-encoder / SVM, WADI MLP) keeps its ``nn.Module`` and trains with stock PyTorch-ROCm
+ops (MIOpen / hipBLASLt) - but inside the same one-process-per-GPU runtime: all floating-point state of all
+co-resident nodes (parameters AND buffers such as BatchNorm running statistics) aliases rows of one ``[K, P]`` slab,
+so model exchange stays "pass a row index" / one RCCL all-to-all of rows, and FedAvg stays the grouped row-reduce
+kernel (``csrc/fedavg.hip``), exactly as for the spec models. Integer buffers (``num_batches_tracked``) stay
+node-local.
+
+Reference behaviour kept: a new optimizer per round (lightninglearner.py:148-160), per-epoch validation, evaluation
+before training, loss / confusion-matrix metrics for classifiers, loss only for the others.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .engine import PHASES, PhaseStats, ShardEngine
+from .slab import ALIGN, ParamLayout, ParamSlot
+
+
+@dataclass
+class ModuleSpec:
+    """What :class:`BatchedFederation` needs to know about a model family that has no kernel-level spec."""
+    name: str
+    factory: Callable[[], torch.nn.Module]      # () -> FederatedModule (reference model class, default arguments)
+    num_classes: int
+    input_shape: tuple                           # per-sample shape the module's forward expects
+
+
+class StateLayout(ParamLayout):
+    """Slab columns for the floating-point entries of a ``state_dict`` (parameters and buffers, in order)."""
+
+    def __init__(self, sd):
+        self.spec = None
+        self.keys: List[str] = list(sd.keys())
+        self.int_keys: List[str] = [k for k, t in sd.items() if not torch.is_floating_point(t)]
+        self.int_shapes = {k: tuple(sd[k].shape) for k in self.int_keys}
+        slots, off = [], 0
+        for name, t in sd.items():
+            if torch.is_floating_point(t):
+                slots.append(ParamSlot(name, tuple(t.shape), off, t.numel()))
+                off += -(-t.numel() // ALIGN) * ALIGN
+        self.slots = slots
+        self.by_name = {s.name: s for s in slots}
+        self.row_stride = max(off, ALIGN)
+        self.num_params = sum(s.numel for s in slots)
+
+    def full_arrays(self, row: torch.Tensor, ints: Dict[str, torch.Tensor]) -> List[np.ndarray]:
+        """Payload of one node: every state_dict entry in order (reference lightninglearner.py:73-89)."""
+        host = row.detach().to("cpu")
+        out = []
+        for k in self.keys:
+            if k in self.by_name:
+                s = self.by_name[k]
+                out.append(host[s.offset:s.offset + s.numel].reshape(s.shape).numpy().copy())
+            else:
+                out.append(ints[k].detach().cpu().numpy().copy())
+        return out
+
+    def arrays_to_row(self, arrays: Sequence, row: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Accepts the full payload (every entry) or only the floating-point ones; returns the integer entries."""
+        if len(arrays) == len(self.keys):
+            named = dict(zip(self.keys, arrays))
+            super().arrays_to_row([named[s.name] for s in self.slots], row)
+            return {k: torch.as_tensor(np.asarray(named[k])) for k in self.int_keys}
+        super().arrays_to_row(arrays, row)
+        return {}
+
+
+class ModuleEngine(ShardEngine):
+    """K independent ``nn.Module`` replicas on one device whose float state aliases the slab rows."""
+
+    def __init__(self, spec: ModuleSpec, n_clients: int, device="cpu", batch_size: int = 32, seed: int = 0,
+                 persist_optimizer: bool = False, client_offset: int = 0):
+        self.spec = spec
+        self.K = int(n_clients)
+        self.device = torch.device(device)
+        self.B = int(batch_size)
+        self.seed = seed
+        self.persist_optimizer = persist_optimizer
+        self.client_offset = int(client_offset)
+        self._perm_calls = 0
+        self.train_x = self.train_y = self.val_x = self.val_y = self.test_x = self.test_y = None
+        self.opt_steps = 0
+        self.params_alt = None
+        torch.manual_seed(seed)
+        self.modules: List[torch.nn.Module] = [spec.factory().to(self.device) for _ in range(self.K)]
+        self.layout = StateLayout(self.modules[0].state_dict())
+        self.params = self.layout.alloc(self.K, self.device)
+        self.classifier = bool(getattr(self.modules[0], "is_classifier", True))
+        self.C = max(int(spec.num_classes), 2)
+        self.stats = {ph: PhaseStats.alloc(self.K, self.C, self.device) for ph in PHASES}
+        for k, m in enumerate(self.modules):
+            tensors = dict(m.named_parameters())
+            tensors.update(dict(m.named_buffers()))
+            for s in self.layout.slots:
+                t = tensors[s.name]
+                view = self.params[k, s.offset:s.offset + s.numel].view(s.shape)
+                view.copy_(t.detach())
+                t.data = view                                    # parameter / buffer now lives in the slab row
+        self.optims = None
+
+    # ------------------------------------------------------------------ parameters
+    def init_params(self, seed: Optional[int] = None, identical: bool = True) -> None:
+        """Modules were initialised by their constructors; ``identical``: every node starts from node 0's
+        weights (the reference's init-model diffusion, node.py:298-299,372-379)."""
+        if identical and self.K > 1:
+            self.params[1:] = self.params[0:1]
+
+    def _ints(self, k: int) -> Dict[str, torch.Tensor]:
+        sd = self.modules[k].state_dict()
+        return {name: sd[name] for name in self.layout.int_keys}
+
+    def get_state_dict(self, k: int):
+        return OrderedDict((n, t.detach().clone()) for n, t in self.modules[k].state_dict().items())
+
+    def set_state_dict(self, k: int, sd) -> None:
+        self.set_arrays(k, [sd[n].detach().cpu().numpy() for n in self.layout.keys])
+
+    def get_arrays(self, k: int) -> List[np.ndarray]:
+        return self.layout.full_arrays(self.params[k], self._ints(k))
+
+    def set_arrays(self, k: int, arrays) -> None:
+        ints = self.layout.arrays_to_row(arrays, self.params[k])
+        own = self.modules[k].state_dict()
+        for name, v in ints.items():
+            own[name].copy_(v.to(own[name].device).reshape(own[name].shape))
+
+    # ------------------------------------------------------------------ data
+    def set_data(self, train_x, train_y, val_x=None, val_y=None, test_x=None, test_y=None) -> None:
+        """``*_x`` [K, n, ...] (reshaped to the module's input shape), ``*_y`` [K, n] (dtype kept)."""
+        def put(x, y):
+            if x is None:
+                return None, None
+            x = x.reshape(self.K, x.shape[1], *self.spec.input_shape).to(self.device, torch.float32).contiguous()
+            return x, y.to(self.device).contiguous()
+        self.train_x, self.train_y = put(train_x, train_y)
+        self.val_x, self.val_y = put(val_x, val_y)
+        self.test_x, self.test_y = put(test_x, test_y)
+
+    # ------------------------------------------------------------------ training / evaluation
+    def reset_optimizer(self) -> None:
+        self.optims = [m.configure_optimizers() for m in self.modules]
+        self.opt_steps = 0
+
+    def _run_phase(self, k, x, y, phase, train, optim=None, order=None) -> None:
+        m, st, C = self.modules[k], self.stats[phase], self.C
+        n = x.shape[0]
+        for s in range(0, n, self.B):
+            idx = order[s:s + self.B] if order is not None else torch.arange(s, min(s + self.B, n), device=self.device)
+            if train and len(idx) < 2:
+                continue                                     # BatchNorm cannot train on a single sample
+            xb, yb = x[idx], y[idx]
+            if self.classifier:
+                yb = yb.long()
+            if train:
+                loss, pred = m.training_loss(xb, yb)
+                optim.zero_grad(set_to_none=True)
+                loss.backward()
+                optim.step()
+            else:
+                with torch.no_grad():
+                    loss, pred = m.training_loss(xb, yb)
+            st.loss_sum[k] += loss.detach() * len(idx)
+            st.count[k] += len(idx)
+            if self.classifier and pred is not None:
+                pred = pred.long().clamp(0, C - 1)
+                yc = yb.clamp(0, C - 1)
+                st.correct[k] += (pred == yc).sum().to(torch.int32)
+                st.confusion[k].view(-1).index_add_(0, yc * C + pred, torch.ones_like(pred, dtype=torch.int32))
+
+    def fit(self, epochs, active=None):
+        if self.optims is None or not self.persist_optimizer:
+            self.reset_optimizer()
+        perms = self._epoch_perms(epochs).to(self.device).long()
+        n = self.train_x.shape[1]
+        out = {}
+        for e in range(epochs):
+            self.stats["Train"].zero_(); self.stats["Validation"].zero_()
+            for k in range(self.K):
+                if active is not None and not bool(active[k]):
+                    continue
+                self.modules[k].train()
+                self._run_phase(k, self.train_x[k], self.train_y[k], "Train", True, self.optims[k], perms[e, k, :n])
+                if self.val_x is not None:
+                    self.modules[k].eval()
+                    self._run_phase(k, self.val_x[k], self.val_y[k], "Validation", False)
+            out = {"Train": self.stats["Train"].summary(), "Validation": self.stats["Validation"].summary()}
+        self.opt_steps += epochs * self.steps_per_epoch()
+        return out
+
+    def evaluate(self):
+        self.stats["Test"].zero_()
+        for k in range(self.K):
+            self.modules[k].eval()
+            self._run_phase(k, self.test_x[k], self.test_y[k], "Test", False)
+        return self.stats["Test"].summary()

@@ -28,7 +28,10 @@ def _scenario(tmp_path, n, federation, dataset, model, rounds, topology="ring"):
 
 @pytest.mark.parametrize("dataset,model,federation,topology", [("MNIST", "CNN", "DFL", "ring"),
                                                                ("MNIST", "MLP", "CFL", "star"),
-                                                               ("FEMNIST", "CNN", "SDFL", "ring")])
+                                                               ("FEMNIST", "CNN", "SDFL", "ring"),
+                                                               # no kernel-level spec: stock ops, state in the slab
+                                                               ("SYSCALL", "MLP", "DFL", "ring"),
+                                                               ("CIFAR10", "simplemobilenet", "DFL", "ring")])
 def test_scenario_on_the_hip_engine(tmp_path, dataset, model, federation, topology):
     from p2pfl_amd.runtime.launch import run_scenario
     cdir = _scenario(tmp_path, 4, federation, dataset, model, rounds=2, topology=topology)

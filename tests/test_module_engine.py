@@ -1,0 +1,117 @@
+"""Batched runtime for model families without a kernel-level spec (runtime/module_engine.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from p2pfl_amd.node_start import build_dataset_and_model, build_model
+from p2pfl_amd.runtime.federation import BatchedFederation
+from p2pfl_amd.runtime.module_engine import ModuleEngine, ModuleSpec, StateLayout
+from p2pfl_amd.utils.topologymanager import TopologyManager
+
+
+def _spec(ds="SYSCALL", model="MLP"):
+    probe = build_dataset_and_model(ds, model, 0, 20)[0]
+    return ModuleSpec(f"{ds}-{model}", lambda: build_model(ds, model), probe.num_classes, tuple(probe.input_shape))
+
+
+def test_state_layout_covers_buffers_and_keeps_integer_entries():
+    m = build_model("SYSCALL", "MLP")
+    sd = m.state_dict()
+    lay = StateLayout(sd)
+    assert "batchnorm1.running_mean" in lay.by_name and lay.int_keys == ["batchnorm1.num_batches_tracked",
+                                                                          "batchnorm2.num_batches_tracked"]
+    assert lay.row_stride % 64 == 0 and all(s.offset % 64 == 0 for s in lay.slots)
+    row = torch.zeros(lay.row_stride)
+    ints = lay.arrays_to_row([v.numpy() for v in sd.values()], row)
+    arrays = lay.full_arrays(row, ints)
+    assert len(arrays) == len(sd)
+    for a, (k, v) in zip(arrays, sd.items()):
+        assert a.shape == tuple(v.shape) and np.allclose(a, v.numpy())
+
+
+def test_module_state_aliases_the_slab_and_training_writes_through():
+    eng = ModuleEngine(_spec(), 3, "cpu", seed=1)
+    shards = [build_dataset_and_model("SYSCALL", "MLP", i, 20)[0] for i in range(3)]
+    eng.set_data(*(torch.stack([s.tensors()[j][:40] for s in shards]) for j in range(6)))
+    eng.init_params()
+    assert torch.equal(eng.params[0], eng.params[2])
+    w = eng.layout.view(eng.params, "l1.weight")
+    assert eng.modules[1].l1.weight.data_ptr() == w[1].data_ptr()
+    rm = eng.layout.view(eng.params, "batchnorm1.running_mean")
+    before = eng.params.clone()
+    l0 = eng.evaluate()["loss"]
+    out = eng.fit(2)
+    assert not torch.equal(before, eng.params) and not torch.equal(rm[0], before[0, :0].new_zeros(rm[0].shape))
+    assert torch.equal(eng.modules[2].batchnorm1.running_mean, rm[2])          # BN statistics live in the row
+    assert (eng.evaluate()["loss"] < l0).all() and out["Train"]["count"].tolist() == [40] * 3
+    # an aggregation result written into the slab is what the modules compute with
+    eng.params[1].copy_(eng.params[0])
+    x = eng.test_x[0][:8]
+    eng.modules[0].eval(); eng.modules[1].eval()
+    assert torch.equal(eng.modules[0](x), eng.modules[1](x))
+    # payload round trip incl. the integer buffers
+    arrays = eng.get_arrays(0)
+    assert len(arrays) == len(eng.modules[0].state_dict()) and arrays[-1].shape == eng.modules[0].l3.bias.shape
+    eng.set_arrays(2, arrays)
+    assert torch.equal(eng.params[2], eng.params[0])
+    assert int(eng.modules[2].batchnorm1.num_batches_tracked) == int(eng.modules[0].batchnorm1.num_batches_tracked)
+
+
+def test_federation_of_batchnorm_models_averages_rows_over_the_train_sets():
+    tm = TopologyManager(n_nodes=4, b_symmetric=True)
+    tm.generate_ring_topology()
+    fed = BatchedFederation(_spec(), tm.topology, device="cpu", epochs=1, seed=3)
+    shards = [build_dataset_and_model("SYSCALL", "MLP", i, 20)[0] for i in range(4)]
+    fed.set_local_data(*(torch.stack([s.tensors()[j][:40] for s in shards]) for j in range(6)))
+    fed.init_params()
+    g = torch.Generator().manual_seed(0)
+    fed.engine.params.copy_(torch.randn(fed.engine.params.shape, generator=g))
+    before = fed.engine.params.clone()
+    fed.aggregate()
+    for i in range(4):
+        ts = [(i - 1) % 4, i, (i + 1) % 4]
+        assert torch.allclose(fed.engine.params[i], before[ts].mean(0), atol=1e-6)
+    rep = fed.run_round()
+    assert rep.train_samples == 4 * 40 and torch.isfinite(fed.engine.params).all()
+
+
+@pytest.mark.parametrize("dataset,model", [("SYSCALL", "MLP"), ("SYSCALL", "Autoencoder"), ("WADI", "MLP")])
+def test_launcher_runs_non_spec_families_with_faults_checkpoints_resume(tmp_path, dataset, model):
+    from p2pfl_amd.controller import Controller
+    from p2pfl_amd.runtime.launch import run_scenario
+    cdir = os.path.join(str(tmp_path), "config", "scen")
+    Controller.generate_participants(cdir, 3, "DFL", dataset, model, rounds=2, epochs=1, accelerator="cpu",
+                                     controller="", overrides={"tracking_args": {"log_dir": str(tmp_path / "logs")}})
+    for i in range(3):
+        path = os.path.join(cdir, f"participant_{i}.json")
+        p = json.load(open(path))
+        p["network_args"]["neighbors"] = " ".join(f"127.0.0.1:{45000 + j}" for j in ((i - 1) % 3, (i + 1) % 3))
+        p["scenario_args"]["name"] = "scen"
+        json.dump(p, open(path, "w"))
+    json.dump([{"round": 1, "action": "kill", "node": 2}], open(os.path.join(cdir, "faults.json"), "w"))
+    s = run_scenario(cdir, device="cpu", save_models=True)
+    assert s["nodes"] == 3 and s["rounds"] == 2 and np.isfinite(s["final_test_loss"])
+    logs = tmp_path / "logs" / "scen"
+    assert "alive False" in open(logs / "participant_2.log").read()
+    os.remove(os.path.join(cdir, "faults.json"))
+    s2 = run_scenario(cdir, device="cpu", rounds=1, resume=str(logs))
+    assert s2["first_round"] == 2 and s2["final_test_loss"] <= s["final_test_loss"] * 1.5 + 1e-3
+
+
+def test_unknown_family_is_refused():
+    from p2pfl_amd.controller import Controller
+    from p2pfl_amd.runtime.launch import run_scenario
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    cdir = os.path.join(tmp, "config", "scen")
+    Controller.generate_participants(cdir, 2, "DFL", "MNIST", "MLP", rounds=1, epochs=1, accelerator="cpu", controller="")
+    for i in range(2):
+        path = os.path.join(cdir, f"participant_{i}.json")
+        p = json.load(open(path))
+        p["model_args"]["model"] = "Transformer"
+        json.dump(p, open(path, "w"))
+    with pytest.raises(ValueError):
+        run_scenario(cdir, device="cpu")

@@ -115,3 +115,43 @@ def test_unknown_family_is_refused():
         json.dump(p, open(path, "w"))
     with pytest.raises(ValueError):
         run_scenario(cdir, device="cpu")
+
+
+# ------------------------------------------------------------------ 2 ranks over gloo
+def _two_rank_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    tm = TopologyManager(n_nodes=6, b_symmetric=True)
+    tm.generate_ring_topology()
+    fed = BatchedFederation(_spec(), tm.topology, device="cpu", epochs=1, seed=3, rank=rank, world_size=world,
+                            process_group=dist.group.WORLD)
+    shards = [build_dataset_and_model("SYSCALL", "MLP", i, 20)[0] for i in fed.local]
+    fed.set_local_data(*(torch.stack([s.tensors()[j][:40] for s in shards]) for j in range(6)))
+    fed.init_params()
+    rows = torch.randn(6, fed.engine.params.shape[1], generator=torch.Generator().manual_seed(0))
+    fed.engine.params.copy_(rows[fed.local.start:fed.local.stop])
+    fed.aggregate()
+    got = fed.engine.params.clone()
+    rep = fed.run_round()                       # and a whole round (training with dropout: finite, not pinned)
+    out[rank] = (got, bool(torch.isfinite(fed.engine.params).all()), rep.exchanged_rows)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_exchange_rows_of_module_state():
+    """Rows of nn.Module state (BatchNorm statistics included) cross the rank boundary like spec-model rows."""
+    import socket
+
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = mp.Manager().dict()
+    mp.spawn(_two_rank_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.cat([out[0][0], out[1][0]], dim=0)
+    rows = torch.randn(6, got.shape[1], generator=torch.Generator().manual_seed(0))
+    for i in range(6):
+        assert torch.allclose(got[i], rows[[(i - 1) % 6, i, (i + 1) % 6]].mean(0), atol=1e-6)
+    assert out[0][1] and out[1][1] and out[0][2] == 2 and out[1][2] == 2

@@ -226,11 +226,18 @@ def conv2_fwd(a1, w, bias, a2, code, ks: int, wprep=None) -> None:
 _wgrad_scratch = {}
 
 
-def conv2_wgrad(g, code, a1, dw, db, ks: int) -> None:
+def conv2_wgrad_scratch(K: int, B: int, ks: int, device) -> Optional[torch.Tensor]:
+    """Scratch buffer :func:`conv2_wgrad` wants for this problem size (None: it needs none). With few clients
+    the batch is split over more blocks and their partial sums go through this buffer."""
+    need = int(load().p2pfl_conv2_wgrad_scratch(K, B, ks))
+    return torch.empty(need, dtype=torch.float32, device=device) if need else None
+
+
+def conv2_wgrad(g, code, a1, dw, db, ks: int, scratch: Optional[torch.Tensor] = None) -> None:
     """Stage-2 weight/bias gradient: dw [K,Cout,Cin*ks*ks], db [K,Cout] (overwritten).
 
-    With few clients the batch is split over more blocks; their partial sums go through a scratch buffer
-    that is kept per (device, stream) - one call per stream is in flight at a time."""
+    ``scratch``: buffer from :func:`conv2_wgrad_scratch` owned by the caller (one call in flight per buffer);
+    without it a module-level buffer per (device, stream, thread) is used."""
     K, B, Cout = g.shape[0], g.shape[1], g.shape[2]
     Cin = a1.shape[2]
     (gp, gs), (ap, as_), (wp, ws), (bp, bs) = _pc(g), _pc(a1), _pc(dw), _pc(db)
@@ -240,10 +247,13 @@ def conv2_wgrad(g, code, a1, dw, db, ks: int) -> None:
     need = int(lib.p2pfl_conv2_wgrad_scratch(K, B, ks))
     sp = 0
     if need:
-        key = (g.device, int(stream or 0), threading.get_ident())   # engines of several threads may share a stream
-        buf = _wgrad_scratch.get(key)
-        if buf is None or buf.numel() < need:
-            buf = _wgrad_scratch[key] = torch.empty(need, dtype=torch.float32, device=g.device)
+        if scratch is not None and scratch.numel() >= need:
+            buf = _t(scratch)
+        else:
+            key = (g.device, int(stream or 0), threading.get_ident())
+            buf = _wgrad_scratch.get(key)
+            if buf is None or buf.numel() < need:
+                buf = _wgrad_scratch[key] = torch.empty(need, dtype=torch.float32, device=g.device)
         sp = buf.data_ptr()
     _chk(lib.p2pfl_conv2_wgrad(gp, gs, cp, cs, ap, as_, wp, ws, bp, bs, sp, need, K, B, Cin, Cout, ks, stream),
          "conv2_wgrad")

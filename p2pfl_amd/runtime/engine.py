@@ -289,6 +289,9 @@ class HipEngine(ShardEngine):
         # tap-major bf16 weight copies of the stage-2 convolutions (refreshed at every forward pass)
         self.wprep = {i: hip.conv2_prep_alloc(K, l.ksize, dev) for i, l in enumerate(self.spec.layers)
                       if l.kind == "conv2pool"}
+        # partial-sum scratch of the batch-split stage-2 weight gradient (small shards only)
+        self.w2_scratch = {i: hip.conv2_wgrad_scratch(K, B, l.ksize, dev) for i, l in enumerate(self.spec.layers)
+                           if l.kind == "conv2pool"}
         self.karange = torch.arange(K, device=dev).unsqueeze(1)
         self._nv_cache: Dict[int, torch.Tensor] = {}
         self._tail_cache: Dict[tuple, torch.Tensor] = {}
@@ -318,6 +321,7 @@ class HipEngine(ShardEngine):
                 ranges.append((pos, L.row_stride))
             self._adam_ranges = ranges
         self._graphs: Dict[tuple, tuple] = {}
+        self._capturing = False
         self._perm_buf = None
         self._bc_buf = None
         self._eval_graph = None
@@ -447,7 +451,7 @@ class HipEngine(ShardEngine):
                 if dy_next is not None:
                     dy = dy_next
             elif l.kind == "conv2pool":
-                hip.conv2_wgrad(dy, self.code[i], self.act[i - 1], gW, gb, l.ksize)
+                hip.conv2_wgrad(dy, self.code[i], self.act[i - 1], gW, gb, l.ksize, scratch=self.w2_scratch[i])
                 hip.conv2_dgrad(dy, self.code[i], W, self.dact[i - 1], l.ksize, wprep=self.wprep[i])
                 dy = self.dact[i - 1]
             else:  # conv1pool (first layer: no data gradient)
@@ -557,7 +561,8 @@ class HipEngine(ShardEngine):
             W, _ = self._w(self.params, l)
             gW, gb = self._w(self.grads, l)
             if l.kind == "conv2pool":
-                hip.conv2_wgrad(self.dact[i], self.code[i], self.act[i - 1], gW, gb, l.ksize)
+                hip.conv2_wgrad(self.dact[i], self.code[i], self.act[i - 1], gW, gb, l.ksize,
+                                scratch=self.w2_scratch[i])
                 hip.conv2_dgrad(self.dact[i], self.code[i], W, self.dact[i - 1], l.ksize, wprep=self.wprep[i])
             else:
                 hip.conv1_wgrad(self.dact[i], self.code[i], data, sidx, gW, gb, l.ksize)
@@ -628,7 +633,12 @@ class HipEngine(ShardEngine):
                 self._eval_pass(self.val_x, self.val_y, "Validation")
 
     def _train(self, epochs: int, steps: int, n: int) -> None:
-        if self.overlap:
+        # The two-stream schedule only ever exists as branches of a captured graph. Launched eagerly (as the
+        # warm-up before a capture used to do, or with use_graph=False) the same stream / event pattern
+        # stalled on the device now and then - always in the first fit of an engine in a long-lived process,
+        # side stream and launch stream both left busy (tests/conftest.py watchdog) - while replays of the
+        # captured graph never did. Eager launches therefore take the in-order schedule.
+        if self.overlap and self._capturing:
             self._train_body_pipelined(epochs, steps, n)
         else:
             self._train_body(epochs, steps, n)
@@ -676,7 +686,11 @@ class HipEngine(ShardEngine):
                     self.v.copy_(snap[2])
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):   # RCCL's watchdog thread may query events meanwhile
-                    self._train(epochs, steps, n)
+                    self._capturing = True
+                    try:
+                        self._train(epochs, steps, n)
+                    finally:
+                        self._capturing = False
                 self._graphs[key] = (g,)
                 self.params.copy_(snap[0]); self.m.copy_(snap[1])
                 if self.v is not None:

@@ -44,12 +44,30 @@ def _stream_watchdog(request):
     def watch():
         if done.wait(limit):
             return
-        print(f"\nSTALL in {request.node.nodeid}", flush=True)
-        for role, st in E.live_aux_streams():
-            print("  stream", role, "idle" if st.query() else "BUSY", flush=True)
-        print("  default stream", "idle" if torch.cuda.default_stream().query() else "BUSY", flush=True)
-        import faulthandler
-        faulthandler.dump_traceback()
+        lines = [f"STALL in {request.node.nodeid} (> {limit:.0f} s)"]
+        try:
+            for role, st in E.live_aux_streams():
+                lines.append(f"  stream {role}: {'idle' if st.query() else 'BUSY'}")
+            lines.append(f"  default stream: {'idle' if torch.cuda.default_stream().query() else 'BUSY'}")
+        except Exception as e:      # the report must get out whatever the runtime says
+            lines.append(f"  (stream query failed: {e!r})")
+        text = "\n".join(lines) + "\n"
+        # pytest captures fds 1 and 2: write the report to a file as well, and to the real terminal
+        try:
+            with open(os.environ.get("P2PFL_STALL_LOG", "gpu_stall_report.log"), "a") as f:
+                f.write(text)
+                import faulthandler
+                faulthandler.dump_traceback(file=f)
+        except OSError:
+            pass
+        capman = request.config.pluginmanager.getplugin("capturemanager")
+        if capman is not None:
+            try:
+                capman.suspend_global_capture(in_=True)
+            except Exception:
+                pass
+        sys.stderr.write("\n" + text)
+        sys.stderr.flush()
         os._exit(3)
 
     t = threading.Thread(target=watch, daemon=True)

@@ -101,7 +101,8 @@ def test_inactive_clients_keep_their_model():
 
 
 def test_pipelined_schedule_matches_single_stream():
-    """Two-stream schedule (conv kernels under the fused wgrad+Adam) == the in-order schedule."""
+    """Two-stream schedule (conv kernels under the fused wgrad+Adam; graph branches) == the in-order schedule
+    (also what an engine with overlap runs when it is not capturing)."""
     from p2pfl_amd.datasets.synthetic import synthetic_shards
     from p2pfl_amd.models.specs import get_spec
     from p2pfl_amd.runtime.engine import HipEngine

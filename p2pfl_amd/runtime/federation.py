@@ -105,6 +105,7 @@ class BatchedFederation:
         """Install the data shards of this rank's nodes. ``n_train_all``: training-set size of EVERY
         node of the scenario (FedAvg weights, node.py:447); default: all equal to the local size."""
         self.engine.set_data(train_x, train_y, val_x, val_y, test_x, test_y)
+        self._plan_cache.clear()         # plans carry the FedAvg weights
         if n_train_all is None:
             self.weights[:] = train_x.shape[1]
         else:
@@ -181,19 +182,26 @@ class BatchedFederation:
     def aggregate(self) -> int:
         """Exchange + FedAvg for the current membership/roles. Returns #rows received from peers."""
         eng = self.engine
-        train_sets, adopt = self._round_structure()
-        if not train_sets:
-            return 0
+        # everything below depends only on (membership, dropped links, roles): planned once per structure - the
+        # Python walk over all nodes of the scenario costs 14 ms for 800 nodes, per round and on every rank
         key = self._structure_key()
-        cached = self._plan_cache.get(key)
+        entry = self._plan_cache.get(key)
+        if entry is None:
+            train_sets, adopt = self._round_structure()
+            if not train_sets:
+                entry = (None, True)
+            else:
+                cached = self._build_exchange(train_sets, adopt)
+                if cached[0] == "rows":
+                    cached = cached[:3] + (cached[3].to(self.device),) + cached[4:]
+                covered = set(train_sets) | set(adopt)
+                entry = (cached, all(i in covered for i in self.local))
+            self._plan_cache[key] = entry
+        cached, all_covered = entry
         if cached is None:
-            cached = self._build_exchange(train_sets, adopt)
-            if cached[0] == "rows":
-                cached = cached[:3] + (cached[3].to(self.device),) + cached[4:]
-            self._plan_cache[key] = cached
+            return 0
         out = eng.alt_slab()
-        covered = set(train_sets) | set(adopt)
-        if any(i not in covered for i in self.local):
+        if not all_covered:
             out.copy_(eng.params)        # rows nobody writes (dead / isolated nodes) keep their model
         if cached[0] == "allreduce":
             _, loc_src, loc_w, loc_dst = cached

@@ -160,13 +160,14 @@ class BaseNode(threading.Thread, Observer):
     def stop(self):
         """Stop the node, its helper threads and every peer link."""
         self._terminate_flag.set()
+        s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         try:   # wake the accept loop
-            s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             s.settimeout(1)
             s.connect((self.host, self.port))
-            s.close()
         except OSError:
             pass
+        finally:
+            s.close()
 
     def run(self):
         logging.info("[BASENODE] Node started")
@@ -246,6 +247,7 @@ class BaseNode(threading.Thread, Observer):
     def connect_to(self, h, p, full=False, force=False):
         """Dial ``h:p``; returns the new :class:`NodeConnection` or None."""
         full_s, force_s = ("1" if full else "0"), ("1" if force else "0")
+        s = nc = None
         try:
             h = socket.gethostbyname(h)
             with self.__nei_lock:
@@ -271,6 +273,11 @@ class BaseNode(threading.Thread, Observer):
                 return None if nc.is_stopped() else nc
         except Exception as e:
             logging.info("%s Can't connect to the node %s:%s (%s)", self.get_name(), h, p, e)
+            if s is not None and nc is None:      # the dial or the handshake failed: nobody owns the socket yet
+                try:
+                    s.close()
+                except OSError:
+                    pass
             return None
 
     def disconnect_from(self, h, p):

@@ -326,9 +326,9 @@ class Controller:
     # ------------------------------------------------------------------ launchers
     def start_node(self, idx):
         cmd = [self.python_path, "-u", "-m", "p2pfl_amd.node_start", os.path.join(self.config_dir, f"participant_{idx}.json")]
-        log = open(os.path.join(self.log_dir, self.scenario_name, f"participant_{idx}.stdout"), "w")
         env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        self.processes.append(subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT, env=env))
+        with open(os.path.join(self.log_dir, self.scenario_name, f"participant_{idx}.stdout"), "w") as log:
+            self.processes.append(subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT, env=env))   # the child keeps its own descriptor
 
     def start_nodes_cmd(self, idx_start_node):
         """One OS process per node; the start node last (reference controller.py:473-485)."""
@@ -348,7 +348,6 @@ class Controller:
         world = int(self.gpus) if self.gpus else max(1, min(n_gpu, self.n_nodes))
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = dict(os.environ, PYTHONPATH=root)
-        log = open(os.path.join(self.log_dir, self.scenario_name, "batched_launcher.log"), "w")
         args = [self.config_dir] + (["--encrypt"] if self.encrypt else [])
         if world > 1:
             cmd = [self.python_path, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
@@ -357,7 +356,8 @@ class Controller:
         else:
             cmd = [self.python_path, "-u", "-m", "p2pfl_amd.runtime.launch"] + args
         logging.info("Launching batched federation: %s", " ".join(cmd))
-        self.processes.append(subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT, env=env))
+        with open(os.path.join(self.log_dir, self.scenario_name, "batched_launcher.log"), "w") as log:
+            self.processes.append(subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT, env=env))
 
     def start_nodes_docker(self, idx_start_node):
         """Generate a compose file (one ROCm container per node, static IPs on a bridge network) and

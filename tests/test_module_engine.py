@@ -110,9 +110,11 @@ def test_unknown_family_is_refused():
     Controller.generate_participants(cdir, 2, "DFL", "MNIST", "MLP", rounds=1, epochs=1, accelerator="cpu", controller="")
     for i in range(2):
         path = os.path.join(cdir, f"participant_{i}.json")
-        p = json.load(open(path))
+        with open(path) as f:
+            p = json.load(f)
         p["model_args"]["model"] = "Transformer"
-        json.dump(p, open(path, "w"))
+        with open(path, "w") as f:
+            json.dump(p, f)
     with pytest.raises(ValueError):
         run_scenario(cdir, device="cpu")
 

@@ -431,7 +431,8 @@ P2PFL_API int p2pfl_linear_fwd(const float* x, long x_cs, const float* w, long w
     // flight per step (100 clients on MI355X: 546 -> 516 us; 128-deep steps cost occupancy: 514-589 us)
     // few clients: at most one block per CU, so the bytes in flight per block bound the bandwidth -> 128-deep
     const bool sparse_grid = (long)grid.x * grid.y * grid.z <= num_cus() && getenv("P2PFL_NO_BK128") == nullptr;
-    // (single-buffered 64- / 128-deep variants: 528 us against 516-528 double-buffered 64-deep; 128-deep x 2: 640)
+    // (single-buffered 64- / 128-deep variants: 528 us against 516-528 double-buffered 64-deep; 128-deep x 2: 640;
+    //  32 x 64 tiles with 2 waves, i.e. twice the blocks: 549 us with 64-deep, 609 us with 128-deep steps)
     if (In >= 1024 && sparse_grid) hipLaunchKernelGGL((linear_fwd_kernel<128, 2>), grid, dim3(256), 0, stream, a);
     else if (In >= 1024) hipLaunchKernelGGL((linear_fwd_kernel<64, 2>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((linear_fwd_kernel<32, 2>), grid, dim3(256), 0, stream, a);

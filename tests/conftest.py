@@ -27,10 +27,10 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture(autouse=True)
 def _stream_watchdog(request):
-    """If a GPU test runs longer than P2PFL_STREAM_WATCHDOG seconds (default 120, 0 = off), report which HIP
+    """If a GPU test runs longer than P2PFL_STREAM_WATCHDOG seconds (default 180, 0 = off), report which HIP
     streams still hold work (the engines' auxiliary streams and the default stream) and leave - a stalled
     device wait cannot be interrupted from Python otherwise."""
-    limit = float(os.environ.get("P2PFL_STREAM_WATCHDOG", "120") or 0)
+    limit = float(os.environ.get("P2PFL_STREAM_WATCHDOG", "180") or 0)
     if limit <= 0 or "gpu" not in request.keywords:
         yield
         return

@@ -227,17 +227,20 @@ struct AdamHyper {
     int fresh;
 };
 
+template <bool FRESH>
 struct EpiWgradAdam {
     float* w; float* mw; float* vw;     // [M][N] weight, first and second moment
     float* b; float* mb; float* vb;     // [M] bias and its moments (column N of the product)
     int M, N;
     float step, beta1, beta2, eps, wd, isb2;
-    bool fresh;                          // first step of a new optimizer: the moments are zero, do not read them
+    // FRESH: first step of a new optimizer - the moments are zero and are not read. A compile-time switch: as a
+    // run-time flag it changed the register allocation of the ordinary step (104 -> 80 VGPRs, i.e. six instead of
+    // four workgroups per CU) and the convolution blocks of the side branch no longer found room beside it.
     __device__ __forceinline__ void upd(float* p, float* m, float* v, float g) const {
         const float pv = *p;
         g += wd * pv;
-        const float mv = beta1 * (fresh ? 0.f : *m) + (1.f - beta1) * g;
-        const float vv = beta2 * (fresh ? 0.f : *v) + (1.f - beta2) * g * g;
+        const float mv = beta1 * (FRESH ? 0.f : *m) + (1.f - beta1) * g;
+        const float vv = beta2 * (FRESH ? 0.f : *v) + (1.f - beta2) * g * g;
         *m = mv; *v = vv;
         *p = pv - step * (mv / (sqrtf(vv) * isb2 + eps));
     }
@@ -249,7 +252,7 @@ struct EpiWgradAdam {
             const size_t o = (size_t)m * N + n;
             f32x4 pv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + o));
             f32x4 mv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (!fresh) {
+            if constexpr (!FRESH) {
                 mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mw + o));
                 vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vw + o));
             }
@@ -287,8 +290,36 @@ struct WgradAdamArgs {
 
 // WR x WC waves: block tile (32 WR) x (128 WC). Wider tiles (WC = 4: 32 x 512) turn the weight/moment
 // traffic of a workgroup into 2 KB row segments instead of 512 B ones (fewer DRAM page activations).
-template <int WR, int WC>
-__global__ __launch_bounds__(256, 2) void linear_wgrad_adam_kernel(WgradAdamArgs a) {
+// Occupancy is pinned to 2 waves per SIMD (two workgroups per CU) on purpose. The kernel is HBM-bound and fastest
+// with two (2.87 ms; three: 2.99 ms), and the register file is shared with the side branch of the step: with three
+// resident workgroups (what its 154 unified VGPRs allow) the 512-thread convolution blocks never find 2 x 64 free
+// VGPRs per SIMD, and the stage-2 weight gradient waits the whole update out (10 clients: 302 -> 341 ms per round
+// after an unrelated loader change had shrunk the allocation from ~176 to 154 registers). amdgpu_waves_per_eu(2, 2)
+// does not pad the allocation, so RegisterReserve keeps N extra VGPRs live from the first to the last instruction.
+template <int N>
+struct RegisterReserve {
+    float r[N];
+    __device__ __forceinline__ RegisterReserve() {
+#pragma unroll
+        for (int i = 0; i < N; ++i) asm volatile("v_mov_b32 %0, 0" : "=v"(r[i]));
+    }
+    __device__ __forceinline__ void release() const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) asm volatile("" ::"v"(r[i]));
+    }
+};
+template <>
+struct RegisterReserve<0> {
+    __device__ __forceinline__ void release() const {}
+};
+constexpr int PIN_UPDATE_MAX_CLIENTS = 80;    // measured: pinned wins by 5-8 % at 20-50 clients, 2 % at 64, ties at 80, loses 1.6 % at 100
+constexpr int UPDATE_KERNEL_RESERVE = 12;      // -> 188 VGPRs: two waves per SIMD, 2 x 64 left for a convolution block
+                                               // (pinned by tests/test_host_sanitizers.py::test_fused_update_occupancy)
+
+template <int WR, int WC, bool FRESH, int RESERVE>
+__global__ __launch_bounds__(256, 2)
+void linear_wgrad_adam_kernel(WgradAdamArgs a) {
+    RegisterReserve<RESERVE> reserve;
     constexpr int BM = 32 * WR, BN = 128 * WC;
     __shared__ GemmSmem<BM, BN, 1> sm;
     const int c = blockIdx.z;
@@ -297,24 +328,25 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_adam_kernel(WgradAdamArgs
     const float ib1 = a.h.bc ? a.h.bc[0] : a.h.inv_bc1;
     const float isb2 = a.h.bc ? a.h.bc[1] : a.h.inv_sqrt_bc2;
     const long wo = c * a.w_cs, bo = c * a.b_cs;
-    EpiWgradAdam epi{a.w + wo, a.mw + wo, a.vw + wo, a.b + bo, a.mb + bo, a.vb + bo, a.Out, a.In,
-                         a.h.lr * ib1, a.h.beta1, a.h.beta2, a.h.eps, a.h.weight_decay, isb2, a.h.fresh != 0};
-    gemm_block_tile<BM, BN, WR, WC, LoadColMajorK, LoadXTOnes, EpiWgradAdam, true, 1>(
+    EpiWgradAdam<FRESH> epi{a.w + wo, a.mw + wo, a.vw + wo, a.b + bo, a.mb + bo, a.vb + bo, a.Out, a.In,
+                            a.h.lr * ib1, a.h.beta1, a.h.beta2, a.h.eps, a.h.weight_decay, isb2};
+    gemm_block_tile<BM, BN, WR, WC, LoadColMajorK, LoadXTOnes, EpiWgradAdam<FRESH>, true, 1>(
         sm, al, bl, epi, blockIdx.y * BM, blockIdx.x * BN, 0, a.B);
+    reserve.release();
 }
 
 // ---------------------------------------------------------------------------------------
 // Weight gradient fused with the SGD-momentum update (the FEMNIST models): same idea, 4 words per weight
 // instead of 7 (gradient write + read and the separate pass over p / buf go away).
 // ---------------------------------------------------------------------------------------
+template <bool FRESH>
 struct EpiWgradSgdm {
     float* w; float* mw; float* b; float* mb;
     int M, N;
     float lr, momentum, wd;
-    bool fresh;
     __device__ __forceinline__ void upd(float* p, float* m, float g) const {
         const float pv = *p;
-        const float mv = momentum * (fresh ? 0.f : *m) + (g + wd * pv);
+        const float mv = momentum * (FRESH ? 0.f : *m) + (g + wd * pv);
         *m = mv;
         *p = pv - lr * mv;
     }
@@ -324,7 +356,7 @@ struct EpiWgradSgdm {
             const size_t o = (size_t)m * N + n;
             f32x4 pv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + o));
             f32x4 mv = {0.f, 0.f, 0.f, 0.f};
-            if (!fresh) mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mw + o));
+            if constexpr (!FRESH) mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mw + o));
             const float* gg = &g.x;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -355,15 +387,16 @@ struct WgradSgdmArgs {
     const int* sidx; long s_cs;
 };
 
-__global__ __launch_bounds__(256, 2) void linear_wgrad_sgdm_kernel(WgradSgdmArgs a) {
+template <bool FRESH>
+__global__ __launch_bounds__(256, 2)
+void linear_wgrad_sgdm_kernel(WgradSgdmArgs a) {
     __shared__ GemmSmem<128, 128, 1> sm;
     const int c = blockIdx.z;
     LoadColMajorK al{a.dy + c * a.dy_cs, a.Out, a.B, a.Out};
     LoadXTOnes bl{a.x + c * a.x_cs, a.In, a.B, a.sidx ? a.sidx + c * a.s_cs : nullptr};
     const long wo = c * a.w_cs, bo = c * a.b_cs;
-    EpiWgradSgdm epi{a.w + wo, a.mw + wo, a.b + bo, a.mb + bo, a.Out, a.In, a.lr, a.momentum, a.weight_decay,
-                     a.fresh != 0};
-    gemm_block_tile<128, 128, 4, 1, LoadColMajorK, LoadXTOnes, EpiWgradSgdm, true, 1>(
+    EpiWgradSgdm<FRESH> epi{a.w + wo, a.mw + wo, a.b + bo, a.mb + bo, a.Out, a.In, a.lr, a.momentum, a.weight_decay};
+    gemm_block_tile<128, 128, 4, 1, LoadColMajorK, LoadXTOnes, EpiWgradSgdm<FRESH>, true, 1>(
         sm, al, bl, epi, blockIdx.y * 128, blockIdx.x * 128, 0, a.B);
 }
 
@@ -395,7 +428,18 @@ P2PFL_API int p2pfl_linear_wgrad_adam(const float* dy, long dy_cs, const float* 
     // 128 x 128 tiles, 2 workgroups per CU: measured best of {128x128, 64x256, 32x512} x {2, 3, 4 per CU}
     // (2.87 / 2.90 / 3.31 ms and 2.87 / 2.99 / 4.09 ms for 100 clients x 3136x2048 on MI355X)
     const dim3 grid(cdiv(In + 1, 128), cdiv(Out, 128), K);
-    hipLaunchKernelGGL((linear_wgrad_adam_kernel<4, 1>), grid, dim3(256), 0, stream, a);
+    // few clients: the side branch of the step is as long as this kernel -> leave its blocks room (see RegisterReserve);
+    // many clients: the side branch has slack and three resident workgroups stream a little faster
+    const char* pin_env = getenv("P2PFL_PIN_UPDATE");
+    const bool pin = pin_env ? atoi(pin_env) != 0 : K <= PIN_UPDATE_MAX_CLIENTS;
+    if (pin) {
+        constexpr int R = UPDATE_KERNEL_RESERVE;
+        if (fresh) hipLaunchKernelGGL((linear_wgrad_adam_kernel<4, 1, true, R>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((linear_wgrad_adam_kernel<4, 1, false, R>), grid, dim3(256), 0, stream, a);
+    } else {
+        if (fresh) hipLaunchKernelGGL((linear_wgrad_adam_kernel<4, 1, true, 0>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((linear_wgrad_adam_kernel<4, 1, false, 0>), grid, dim3(256), 0, stream, a);
+    }
     P2PFL_RETURN_LAST_ERROR();
 }
 
@@ -407,7 +451,8 @@ P2PFL_API int p2pfl_linear_wgrad_sgdm(const float* dy, long dy_cs, const float* 
     WgradSgdmArgs a{dy, dy_cs, x, x_cs, w, mw, w_cs, b, mb, b_cs, B, In, Out, lr, momentum, weight_decay, fresh,
                     sidx, s_cs};
     const dim3 grid(cdiv(In + 1, 128), cdiv(Out, 128), K);
-    hipLaunchKernelGGL(linear_wgrad_sgdm_kernel, grid, dim3(256), 0, stream, a);
+    if (fresh) hipLaunchKernelGGL(linear_wgrad_sgdm_kernel<true>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(linear_wgrad_sgdm_kernel<false>, grid, dim3(256), 0, stream, a);
     P2PFL_RETURN_LAST_ERROR();
 }
 

@@ -145,9 +145,11 @@ class ShardEngine:
         n = self.train_x.shape[1]
         steps = self.steps_per_epoch()
         i64 = torch.int64
-        e = torch.arange(epochs, dtype=i64).view(-1, 1, 1)
-        k = (torch.arange(self.K, dtype=i64) + self.client_offset).view(1, -1, 1)
-        i = torch.arange(n, dtype=i64).view(1, 1, -1)
+        dev = self.device          # integer hash + argsort run where the engine lives (3.7 ms of host time per
+        #                            round for 100 x 540 x 3 on the CPU; wrap-around int64 arithmetic is identical)
+        e = torch.arange(epochs, dtype=i64, device=dev).view(-1, 1, 1)
+        k = (torch.arange(self.K, dtype=i64, device=dev) + self.client_offset).view(1, -1, 1)
+        i = torch.arange(n, dtype=i64, device=dev).view(1, 1, -1)
         x = i * -7046029254386353131                                                      # 0x9E3779B97F4A7C15 as int64
         c = (self._perm_calls * 1442695040888963407 + int(self.seed) * 3935559000370003845) & 0xFFFFFFFFFFFFFFFF
         c = c - (1 << 64) if c >= (1 << 63) else c                                          # python int -> int64 wrap
@@ -158,7 +160,7 @@ class ShardEngine:
         self._perm_calls += 1
         perm = x.argsort(dim=2).to(torch.int32)
         if steps * self.B != n:   # wrap around: the extra rows are masked out through n_valid
-            perm = perm[:, :, torch.arange(steps * self.B) % n]
+            perm = perm[:, :, torch.arange(steps * self.B, device=dev) % n]
         return perm.contiguous()
 
     # ------------------------------------------------------------------ contract

@@ -40,3 +40,33 @@ def test_host_runtime_asan_ubsan(tmp_path):
 
 def test_host_runtime_tsan(tmp_path):
     _build_and_run(tmp_path, ["-fsanitize=thread", "-static-libtsan"])
+
+
+def test_fused_update_occupancy():
+    """The pinned variant of the fused wgrad+Adam kernel must stay at two waves per SIMD with <= 192 VGPRs (room for
+    a 2 x 64-VGPR convolution block of the side branch beside two of its workgroups, see csrc/linear.hip); the
+    allocation is whatever the compiler makes of the source, so it is checked at build time."""
+    import os
+    import re
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "p2pfl_amd", "csrc", "linear.hip")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", src, "-o", os.devnull,
+                          "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    blocks = re.split(r"remark: Function Name: ", out.stderr)
+    seen = {}
+    for b in blocks[1:]:
+        name = b.split()[0]
+        m = re.search(r"linear_wgrad_adam_kernelILi4ELi1ELb([01])ELi(\d+)E", name)
+        if m:
+            vg = int(re.search(r" VGPRs: (\d+)", b).group(1))
+            occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
+            seen[(m.group(1), int(m.group(2)) > 0)] = (vg, occ)
+    assert len(seen) == 4, seen
+    for (fresh, pinned), (vg, occ) in seen.items():
+        if pinned:
+            assert occ == 2 and vg <= 192, (fresh, vg, occ)
+        else:
+            assert occ >= 2, (fresh, vg, occ)

@@ -669,7 +669,9 @@ class HipEngine(ShardEngine):
         saved = None
         if active is not None and not bool(torch.as_tensor(active).all()):
             inactive = (~torch.as_tensor(active, dtype=torch.bool)).nonzero().flatten().to(self.device)
-            saved = (inactive, self.params[inactive].clone())
+            saved = [inactive, self.params[inactive].clone()]
+            if self.persist_optimizer:       # a node that sits the round out keeps its optimizer state as well
+                saved += [self.m[inactive].clone(), None if self.v is None else self.v[inactive].clone()]
         if self.use_graph:
             key = (epochs, steps, n, self.persist_optimizer)
             if key not in self._graphs:
@@ -703,6 +705,10 @@ class HipEngine(ShardEngine):
         self.opt_steps += total
         if saved is not None:
             self.params[saved[0]] = saved[1]
+            if len(saved) > 2:
+                self.m[saved[0]] = saved[2]
+                if saved[3] is not None:
+                    self.v[saved[0]] = saved[3]
         out = {"Train": self.stats["Train"].summary()}
         if self.val_x is not None:
             out["Validation"] = self.stats["Validation"].summary()

@@ -100,6 +100,21 @@ def test_inactive_clients_keep_their_model():
     assert not torch.equal(h.params[0], before[0])
 
 
+def test_inactive_clients_keep_persistent_optimizer_state():
+    from p2pfl_amd.datasets.synthetic import synthetic_shards
+    from p2pfl_amd.models.specs import get_spec
+    from p2pfl_amd.runtime.engine import HipEngine
+    spec = get_spec("mnist-cnn")
+    h = HipEngine(spec, 3, "cuda", seed=7, persist_optimizer=True)
+    h.init_params(identical=False)
+    h.set_data(*synthetic_shards(3, 64, 16, 32, spec.num_classes, seed=5, device="cuda"))
+    h.fit(1)
+    p, m, v = h.params.clone(), h.m.clone(), h.v.clone()
+    h.fit(1, active=torch.tensor([True, False, True]))
+    assert torch.equal(h.params[1], p[1]) and torch.equal(h.m[1], m[1]) and torch.equal(h.v[1], v[1])
+    assert not torch.equal(h.m[0], m[0]) and not torch.equal(h.params[2], p[2])
+
+
 def test_pipelined_schedule_matches_single_stream():
     """Two-stream schedule (conv kernels under the fused wgrad+Adam; graph branches) == the in-order schedule
     (also what an engine with overlap runs when it is not capturing)."""

@@ -101,7 +101,7 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
         from .module_engine import ModuleSpec
         probe = build_dataset_and_model(key[0], key[1], 0, n, root_dir)[0]
         spec = ModuleSpec(f"{key[0]}-{key[1]}", lambda: build_model(key[0], key[1]), int(probe.num_classes),
-                          tuple(probe.input_shape))
+                          tuple(probe.input_shape), augment=getattr(probe, "augment", None))
     scenario = p0["scenario_args"]["name"] or os.path.basename(os.path.normpath(config_dir))
     federation = p0["scenario_args"]["federation"]
     roles = [p["device_args"]["role"] for p in parts]

@@ -32,6 +32,7 @@ class ModuleSpec:
     factory: Callable[[], torch.nn.Module]      # () -> FederatedModule (reference model class, default arguments)
     num_classes: int
     input_shape: tuple                           # per-sample shape the module's forward expects
+    augment: Optional[Callable] = None           # training-batch augmentation of the data module (CIFAR-10 crop / flip)
 
 
 class StateLayout(ParamLayout):
@@ -161,6 +162,8 @@ class ModuleEngine(ShardEngine):
             if self.classifier:
                 yb = yb.long()
             if train:
+                if self.spec.augment is not None:
+                    xb = self.spec.augment(xb)
                 loss, pred = m.training_loss(xb, yb)
                 optim.zero_grad(set_to_none=True)
                 loss.backward()

@@ -34,7 +34,7 @@ from p2pfl_amd.utils.topologymanager import TopologyManager  # noqa: E402
 
 # measured with `python bench.py --impl eager` on one MI355X: the
 # reference-equivalent per-node eager PyTorch loop, client samples/sec on the same config
-EAGER_BASELINE_SAMPLES_PER_SEC = 30324.8   # profiles/r1_eager_baseline.json (1x MI355X, fp32, 100 nodes)
+EAGER_BASELINE_SAMPLES_PER_SEC = 35784.4   # profiles/r1_eager_baseline.json (1x MI355X, fp32, 100 nodes; re-measured at v14)
 
 
 # the other BASELINE.json configurations (the default flags are #4 without encryption/churn = the headline)

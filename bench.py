@@ -134,6 +134,7 @@ def main() -> None:
         for v in victims:
             fed.schedule_fault(args.warmup + 1, "kill", v)
             fed.schedule_fault(args.warmup + 3, "revive", v)
+    fed.prepare()                          # graph capture / lazy loading / planning happen here even with --warmup 0
     for _ in range(args.warmup):
         fed.run_round(sync_timing=False)
     sync()

@@ -714,6 +714,22 @@ class HipEngine(ShardEngine):
             out["Validation"] = self.stats["Validation"].summary()
         return out
 
+    def prepare(self, epochs: int) -> None:
+        """Build everything a round needs ahead of time - lazy kernel loading, buffers, the captured training
+        and evaluation graphs - by running one round and putting parameters, optimizer state, step and shuffle
+        counters back, so the first real round costs what every other round costs."""
+        snap = (self.params.clone(), self.m.clone(), None if self.v is None else self.v.clone(), self.opt_steps,
+                self._perm_calls)
+        self.evaluate()
+        self.fit(epochs)
+        self.synchronize()
+        self.params.copy_(snap[0]); self.m.copy_(snap[1])
+        if self.v is not None:
+            self.v.copy_(snap[2])
+        self.opt_steps, self._perm_calls = snap[3], snap[4]
+        for st in self.stats.values():
+            st.zero_()
+
     def _eval_body(self) -> None:
         self.stats["Test"].zero_()
         self._eval_pass(self.test_x, self.test_y, "Test")

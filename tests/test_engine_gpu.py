@@ -115,6 +115,27 @@ def test_inactive_clients_keep_persistent_optimizer_state():
     assert not torch.equal(h.m[0], m[0]) and not torch.equal(h.params[2], p[2])
 
 
+def test_prepare_leaves_no_trace():
+    """prepare() captures the graphs with a dry-run round; training afterwards == training without it."""
+    from p2pfl_amd.datasets.synthetic import synthetic_shards
+    from p2pfl_amd.models.specs import get_spec
+    from p2pfl_amd.runtime.engine import HipEngine
+    spec = get_spec("mnist-mlp")
+    data = synthetic_shards(3, 64, 16, 32, spec.num_classes, seed=5, device="cuda")
+    res = []
+    for prep in (False, True):
+        h = HipEngine(spec, 3, "cuda", seed=7)
+        h.init_params(identical=False)
+        h.set_data(*data)
+        if prep:
+            p0 = h.params.clone()
+            h.prepare(2)
+            assert torch.equal(h.params, p0) and h.opt_steps == 0 and len(h._graphs) == 1
+        h.fit(2)
+        res.append(h.params.clone())
+    assert torch.equal(res[0], res[1])
+
+
 def test_pipelined_schedule_matches_single_stream():
     """Two-stream schedule (conv kernels under the fused wgrad+Adam; graph branches) == the in-order schedule
     (also what an engine with overlap runs when it is not capturing)."""

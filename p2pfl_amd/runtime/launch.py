@@ -135,6 +135,7 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
             fed.engine.set_arrays(k, arrays)
             first_round = max(first_round, int((meta or {}).get("round", 0)))
 
+    fed.prepare()       # captured graphs / exchange plan before round 0 (models and counters stay as they are)
     log_root = os.path.join(p0["tracking_args"].get("log_dir") or "logs", scenario)
     os.makedirs(log_root, exist_ok=True)
     loggers = {i: CSVLogger(log_root, name="metrics", version=f"participant_{i}") for i in fed.local}

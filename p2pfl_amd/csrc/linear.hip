@@ -16,6 +16,7 @@ struct LinearArgs {
     float* y;        long y_cs;   // [K][B][Out]
     int B, In, Out, relu, vec;
     const int* sidx; long s_cs;   // optional [K][B] row indices into x (x is then the whole [K][n][In] data set)
+    float* part;                  // skinny kernel with gridDim.x > 1: raw partial tiles [K][row tiles][split][NT][16][64]
 };
 
 struct EpiBiasAct {
@@ -69,12 +70,18 @@ __global__ __launch_bounds__(1024) void linear_fwd_skinny_kernel(LinearArgs a) {
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-    const int nsteps = (a.In + 15) / 16;           // 16-deep k-steps, dealt round-robin to the waves
-    for (int s0 = wave; s0 < nsteps; s0 += 16 * U) {
+    // 16-deep k-steps; blockIdx.x owns a contiguous range of them (split reduction over blocks when there are
+    // fewer (client, row tile) pairs than CUs), dealt round-robin to the waves
+    const int nsteps_all = (a.In + 15) / 16;
+    const int per_split = (nsteps_all + gridDim.x - 1) / gridDim.x;
+    const int s_begin = blockIdx.x * per_split;
+    const int nsteps = min(nsteps_all, s_begin + per_split);
+    for (int s0 = s_begin + wave; s0 < nsteps; s0 += 16 * U) {
         float xv[U][8], wv[U][NT][8];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int k = (s0 + 16 * u) * 16 + kq;  // past the end: the loaders return zeros
+            // past the end of this block's range: zeros (the loaders also return zeros past In)
+            const int k = (s0 + 16 * u < nsteps) ? (s0 + 16 * u) * 16 + kq : a.In;
             xl.load8(m0 + r, k, xv[u]);
 #pragma unroll
             for (int j = 0; j < NT; ++j) wl.load8(j * 32 + r, k, wv[u][j]);
@@ -99,6 +106,32 @@ __global__ __launch_bounds__(1024) void linear_fwd_skinny_kernel(LinearArgs a) {
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < 16; ++w) v += red[w][e_out][lane];
+        if (gridDim.x > 1) {       // raw partial tile; linear_skinny_reduce_kernel finishes the job
+            const size_t tile = (((size_t)c * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NT + j;
+            a.part[tile * 1024 + threadIdx.x] = v;
+            continue;
+        }
+        const int m = m0 + mfma_row(e_out, lane), n = j * 32 + r;
+        if (m < a.B && n < a.Out) {
+            v += bias[n];
+            if (a.relu) v = fmaxf(v, 0.f);
+            y[(size_t)m * a.Out + n] = v;
+        }
+    }
+}
+
+// Sum of the split partial tiles + bias (+ ReLU): one block per (client, row tile), thread = (accumulator, lane).
+template <int NT>
+__global__ __launch_bounds__(1024) void linear_skinny_reduce_kernel(LinearArgs a, int ksplit) {
+    const int c = blockIdx.z, m0 = blockIdx.y * 32;
+    const int lane = threadIdx.x & 63, e_out = threadIdx.x >> 6, r = lane & 31;
+    const float* p = a.part + ((size_t)c * gridDim.y + blockIdx.y) * ksplit * NT * 1024 + threadIdx.x;
+    float* y = a.y + c * a.y_cs;
+    const float* bias = a.b + c * a.b_cs;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        float v = 0.f;
+        for (int s = 0; s < ksplit; ++s) v += p[((size_t)s * NT + j) * 1024];
         const int m = m0 + mfma_row(e_out, lane), n = j * 32 + r;
         if (m < a.B && n < a.Out) {
             v += bias[n];
@@ -456,19 +489,43 @@ P2PFL_API int p2pfl_linear_wgrad_sgdm(const float* dy, long dy_cs, const float* 
     P2PFL_RETURN_LAST_ERROR();
 }
 
+// blocks the skinny kernel splits the reduction of one (client, row tile) over: up to 8, while the grid stays
+// below one block per CU and every block keeps >= 16 k-steps per wave round
+static int skinny_splits(int K, int B, int In) {
+    const long tiles = (long)K * cdiv(B, 32);
+    int ks = 1;
+    while (ks < 8 && tiles * ks * 2 <= num_cus() && (In + 15) / 16 / (ks * 2) >= 16) ks *= 2;
+    return ks;
+}
+
+// floats of scratch p2pfl_linear_fwd wants for this problem (0: none)
+P2PFL_API long p2pfl_linear_fwd_scratch(int K, int B, int In, int Out) {
+    if (K <= 0 || B <= 0 || !(Out <= 64 && In >= 512 && (long)K * cdiv(B, 32) <= 2L * num_cus())) return 0;
+    const int ks = skinny_splits(K, B, In);
+    return ks > 1 ? (long)K * cdiv(B, 32) * ks * (Out <= 32 ? 1 : 2) * 1024 : 0;
+}
+
 P2PFL_API int p2pfl_linear_fwd(const float* x, long x_cs, const float* w, long w_cs, const float* b,
                                long b_cs, float* y, long y_cs, int K, int B, int In, int Out,
-                               int relu, const int* sidx, long s_cs, hipStream_t stream) {
+                               int relu, const int* sidx, long s_cs, float* scratch, long scratch_floats,
+                               hipStream_t stream) {
     if (K <= 0 || B <= 0 || In <= 0 || Out <= 0) return -1;
     // float4 loads need In % 4 == 0 and 16-B aligned bases/strides; otherwise element loads
     const int xv = !((In & 3) || (x_cs & 3) || ((uintptr_t)x & 15));
     const int wv = !((In & 3) || (w_cs & 3) || ((uintptr_t)w & 15));
-    LinearArgs a{x, x_cs, w, w_cs, b, b_cs, y, y_cs, B, In, Out, relu, xv | (wv << 1), sidx, s_cs};
+    LinearArgs a{x, x_cs, w, w_cs, b, b_cs, y, y_cs, B, In, Out, relu, xv | (wv << 1), sidx, s_cs, scratch};
     // (with >= 2 tiles per CU the tiled kernel hides the latency itself: 1000 clients x 3136 -> 62: 259 vs 300 us)
     if (Out <= 64 && In >= 512 && (long)K * cdiv(B, 32) <= 2L * num_cus()) {
-        const dim3 sgrid(1, cdiv(B, 32), K);
-        if (Out <= 32) hipLaunchKernelGGL((linear_fwd_skinny_kernel<1, 4>), sgrid, dim3(1024), 0, stream, a);
+        int ks = skinny_splits(K, B, In);
+        const int nt = Out <= 32 ? 1 : 2;
+        if (scratch == nullptr || scratch_floats < (long)K * cdiv(B, 32) * ks * nt * 1024) ks = 1;
+        const dim3 sgrid(ks, cdiv(B, 32), K), rgrid(1, cdiv(B, 32), K);
+        if (nt == 1) hipLaunchKernelGGL((linear_fwd_skinny_kernel<1, 4>), sgrid, dim3(1024), 0, stream, a);
         else hipLaunchKernelGGL((linear_fwd_skinny_kernel<2, 2>), sgrid, dim3(1024), 0, stream, a);
+        if (ks > 1) {
+            if (nt == 1) hipLaunchKernelGGL(linear_skinny_reduce_kernel<1>, rgrid, dim3(1024), 0, stream, a, ks);
+            else hipLaunchKernelGGL(linear_skinny_reduce_kernel<2>, rgrid, dim3(1024), 0, stream, a, ks);
+        }
         P2PFL_RETURN_LAST_ERROR();
     }
     dim3 grid(cdiv(Out, 128), cdiv(B, 32), K);

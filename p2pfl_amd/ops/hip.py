@@ -51,7 +51,8 @@ P, L, I, F = c_void_p, c_long, c_int, c_float
 
 
 class _Sig:
-    p2pfl_linear_fwd = [P, L, P, L, P, L, P, L, I, I, I, I, I, P, L, P]
+    p2pfl_linear_fwd = [P, L, P, L, P, L, P, L, I, I, I, I, I, P, L, P, L, P]
+    p2pfl_linear_fwd_scratch = [I, I, I, I]
     p2pfl_linear_dgrad = [P, L, P, L, P, L, P, L, I, I, I, I, P]
     p2pfl_linear_wgrad = [P, L, P, L, P, L, P, L, I, I, I, I, P, L, P]
     p2pfl_linear_wgrad_adam = [P, L, P, L, P, P, P, L, P, P, P, L, I, I, I, I, F, F, F, F, F, I, P, I, P, L, P]
@@ -103,17 +104,41 @@ def _pc(t: Optional[torch.Tensor], dtype=torch.float32):
 
 
 # ----------------------------------------------------------------------------- linear
-def linear_fwd(x, w, b, y, relu: bool, sidx=None) -> None:
+_fwd_scratch = {}
+
+
+def linear_fwd_scratch(K: int, B: int, In: int, Out: int, device) -> Optional[torch.Tensor]:
+    """Scratch buffer :func:`linear_fwd` wants for this problem (None: none) - skinny heads with few clients split
+    their reduction over several blocks whose partial tiles go through it."""
+    need = int(load().p2pfl_linear_fwd_scratch(K, B, In, Out))
+    return torch.empty(need, dtype=torch.float32, device=device) if need else None
+
+
+def linear_fwd(x, w, b, y, relu: bool, sidx=None, scratch: Optional[torch.Tensor] = None) -> None:
     """y[k] = act(x[k] @ w[k].T + b[k]);  x [K,B,In], w [K,Out,In], b [K,Out], y [K,B,Out].
 
     ``sidx`` [K,B] int32: x is the whole data set [K,n,In] and row r of the product is x[k, sidx[k, r]] (the
-    mini-batch gather of a first dense layer happens in the operand loader)."""
+    mini-batch gather of a first dense layer happens in the operand loader). ``scratch``: buffer from
+    :func:`linear_fwd_scratch` owned by the caller; without it one per (device, stream, thread) is kept here."""
     K, B, Out = y.shape
     In = x.shape[2]
     assert w.shape == (K, Out, In) and b.shape == (K, Out) and (sidx is not None or x.shape[1] == B)
     (xp, xs), (wp, ws), (bp, bs), (yp, ys), (sp, ss) = _pc(x), _pc(w), _pc(b), _pc(y), _pc(sidx, torch.int32)
     assert sidx is None or sidx.shape == (K, B)
-    _chk(load().p2pfl_linear_fwd(xp, xs, wp, ws, bp, bs, yp, ys, K, B, In, Out, int(relu), sp, ss, _stream()),
+    lib = load()
+    stream = _stream()
+    need = int(lib.p2pfl_linear_fwd_scratch(K, B, In, Out))
+    cp = 0
+    if need:
+        if scratch is not None and scratch.numel() >= need:
+            buf = _t(scratch)
+        else:
+            key = (y.device, int(stream or 0), threading.get_ident())
+            buf = _fwd_scratch.get(key)
+            if buf is None or buf.numel() < need:
+                buf = _fwd_scratch[key] = torch.empty(need, dtype=torch.float32, device=y.device)
+        cp = buf.data_ptr()
+    _chk(lib.p2pfl_linear_fwd(xp, xs, wp, ws, bp, bs, yp, ys, K, B, In, Out, int(relu), sp, ss, cp, need, stream),
          "linear_fwd")
 
 

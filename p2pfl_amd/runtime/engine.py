@@ -288,6 +288,7 @@ class HipEngine(ShardEngine):
         # evaluation runs with its own, larger batch (forward only: no gradient buffers) so that the big
         # dense layer streams its weights once per up to EVAL_B rows instead of once per 32
         self._eval_bufs: Dict[int, tuple] = {}
+        self._fwd_scratch: Dict[tuple, Optional[torch.Tensor]] = {}
         # tap-major bf16 weight copies of the stage-2 convolutions (refreshed at every forward pass)
         self.wprep = {i: hip.conv2_prep_alloc(K, l.ksize, dev) for i, l in enumerate(self.spec.layers)
                       if l.kind == "conv2pool"}
@@ -380,6 +381,13 @@ class HipEngine(ShardEngine):
             self._eval_bufs[B] = self._alloc_acts(B) + (B,)
         return self._eval_bufs[B]
 
+    def _linear_fwd(self, x, W, b, y, relu, sidx=None) -> None:
+        """hip.linear_fwd with an engine-owned scratch buffer per problem shape (made at the first, eager, call)."""
+        key = (y.shape[1], W.shape[2], W.shape[1])
+        if key not in self._fwd_scratch:
+            self._fwd_scratch[key] = self.hip.linear_fwd_scratch(self.K, *key, self.device)
+        self.hip.linear_fwd(x, W, b, y, relu, sidx=sidx, scratch=self._fwd_scratch[key])
+
     # ------------------------------------------------------------------ helpers
     def _w(self, slab, l):
         return self.layout.view2d(slab, l.weight), self.layout.view(slab, l.bias)
@@ -417,9 +425,9 @@ class HipEngine(ShardEngine):
                 hip.conv2_fwd(x, W, b, act[i], code[i], l.ksize, wprep=self.wprep[i])
             else:
                 if x is None:      # first layer: the mini-batch rows are gathered by the kernel's operand loader
-                    hip.linear_fwd(data if sidx is not None else data[:, :B], W, b, act[i], l.relu, sidx=sidx)
+                    self._linear_fwd(data if sidx is not None else data[:, :B], W, b, act[i], l.relu, sidx=sidx)
                 else:
-                    hip.linear_fwd(x.flatten(2) if x.dim() > 3 else x, W, b, act[i], l.relu)
+                    self._linear_fwd(x.flatten(2) if x.dim() > 3 else x, W, b, act[i], l.relu)
             x = act[i]
         st = self.stats[phase]
         hip.softmax_ce(x, labels, sidx, self.dact[-1] if train else None, st.loss_sum, st.correct, st.count,
@@ -579,7 +587,7 @@ class HipEngine(ShardEngine):
         x = conv_out.flatten(2)
         for i in range(nc, len(layers)):
             W, b = self._w(self.params, layers[i])
-            hip.linear_fwd(x, W, b, self.act[i], layers[i].relu)
+            self._linear_fwd(x, W, b, self.act[i], layers[i].relu)
             x = self.act[i]
         st = self.stats["Train"]
         hip.softmax_ce(x, labels, sidx, self.dact[-1], st.loss_sum, st.correct, st.count, st.confusion, n_valid)

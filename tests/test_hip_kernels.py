@@ -48,7 +48,10 @@ def route(g, code, P):
                                              (2, 32, 3136, 2048, True), (1, 5, 36, 7, False),
                                              # skinny heads (split-reduction kernel): aligned, 2 col tiles, ragged
                                              (3, 32, 2048, 10, False), (2, 32, 2048, 62, False),
-                                             (2, 45, 1001, 33, True), (1, 7, 515, 64, True)])
+                                             (2, 45, 1001, 33, True), (1, 7, 515, 64, True),
+                                             # reduction split over blocks (few clients): 8 / 4 / 2 splits
+                                             (10, 32, 2048, 10, False), (50, 32, 3136, 62, False),
+                                             (100, 32, 2048, 10, True), (3, 70, 3137, 62, True)])
 def test_linear_fwd(K, B, In, Out, relu):
     h = hip()
     x = torch.randn(K, B, In, device=DEV)

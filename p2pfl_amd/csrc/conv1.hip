@@ -369,8 +369,8 @@ P2PFL_API int p2pfl_conv1_wgrad(const float* g, long g_cs, const uint8_t* code, 
     // dw/db are accumulated with atomics: the caller zeroes them first (p2pfl_zero_rows).
     // float4 / word loads of the pooled gradient and the codes of an image
     if (((uintptr_t)g & 15) || (g_cs & 3) || ((uintptr_t)code & 3) || (c_cs & 3)) return -2;
-    // blocks per client: enough to put ~3 blocks on every CU, at most one per image
-    int splits = cdiv(768, K);
+    // blocks per client: about 1.5 per CU over the launch, at most one per image (more blocks = more atomics)
+    int splits = cdiv(384, K);     // measured (7x7; 10 / 50 / 100 clients): target 256: 49 / 63 / 107 us, 384: 63 / 63 / 91, 512: 63 / 67 / 87, 768: 63 / 88 / 110, 1536: 64 / 124 / 140
     if (splits > B) splits = B;
     if (splits < 1) splits = 1;
     Conv1WgradArgs a{g, g_cs, code, c_cs, data, data_cs, sidx, sidx_cs, dw, dw_cs, db, db_cs, B, F};

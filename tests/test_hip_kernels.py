@@ -286,7 +286,7 @@ def test_conv2_wgrad_dgrad(ks, B, K):
         assert rel_err(da1[k], ref_x) < 2e-2
 
 
-@pytest.mark.parametrize("C,B,nv", [(10, 32, 32), (62, 32, 28), (10, 100, 77)])
+@pytest.mark.parametrize("C,B,nv", [(10, 32, 32), (62, 32, 28), (10, 100, 77), (62, 256, 200), (17, 40, 40), (64, 5, 3)])
 def test_softmax_ce(C, B, nv):
     h = hip()
     K, n = 4, 200

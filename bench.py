@@ -11,8 +11,14 @@ Launch:  python bench.py --gpus 1 --steps K --warmup W
 Scaling is weak by default: every GPU hosts ``--nodes-per-gpu`` (100) federation nodes of one
 N x 100-node random-topology scenario, so N = 1 is exactly the named 100-node configuration.
 Data is synthetic MNIST-shaped (reference shard sizes for a 100-node split: 540 train / 60 val /
-100 test per node), weights are random-init; compute is bf16 MFMA with fp32 accumulation, fp32
-master weights and fp32 Adam moments.
+100 test per node), weights are random-init. Compute precision is fp32 end to end by default, like the
+reference (its Trainer runs 32-bit: fedstellar/learning/pytorch/lightninglearner.py:182-193): fp32 operands on
+v_mfma_f32_32x32x2_f32, fp32 master weights, fp32 Adam moments. ``--dtype bf16`` selects the labelled fast mode
+(operands rounded to bf16, fp32 accumulation) and is reported as such in the JSON line.
+
+``vs_baseline``: the reference publishes no numbers, so the ratio is taken against the
+reference-equivalent eager PyTorch fp32 loop measured by THIS script (``--impl eager --save-baseline`` writes
+profiles/eager_baseline.json, which is read back here); null when that file is absent or for other presets.
 """
 from __future__ import annotations
 
@@ -32,9 +38,18 @@ from p2pfl_amd.models.specs import get_spec  # noqa: E402
 from p2pfl_amd.runtime.federation import BatchedFederation  # noqa: E402
 from p2pfl_amd.utils.topologymanager import TopologyManager  # noqa: E402
 
-# measured with `python bench.py --impl eager` on one MI355X: the
-# reference-equivalent per-node eager PyTorch loop, client samples/sec on the same config
-EAGER_BASELINE_SAMPLES_PER_SEC = 35784.4   # profiles/r1_eager_baseline.json (1x MI355X, fp32, 100 nodes; re-measured at v14)
+# written by `python bench.py --impl eager --save-baseline` on one MI355X: the
+# reference-equivalent per-node eager PyTorch fp32 loop, client samples/sec on the headline config
+BASELINE_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "eager_baseline.json")
+
+
+def eager_baseline_samples_per_sec():
+    try:
+        with open(BASELINE_FILE) as f:
+            rec = json.load(f)
+        return float(rec["value"]) / max(int(rec.get("n_gpus", 1)), 1)
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 # the other BASELINE.json configurations (the default flags are #4 without encryption/churn = the headline)
@@ -75,6 +90,10 @@ def main() -> None:
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--batch-size", type=int, default=32)
     ap.add_argument("--impl", default="hip", choices=["hip", "eager"])
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="precision of the matrix products of the HIP engine (fp32 = the reference's precision)")
+    ap.add_argument("--save-baseline", action="store_true",
+                    help="with --impl eager on the headline config: record the result as profiles/eager_baseline.json")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--encrypt", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -114,7 +133,7 @@ def main() -> None:
     fed = BatchedFederation(spec, topo, federation=args.federation, device=device, engine=args.impl,
                             batch_size=args.batch_size, epochs=args.epochs, seed=args.seed, rank=rank,
                             world_size=world, process_group=pg, encrypt=args.encrypt,
-                            use_graph=not args.no_graph, overlap=not args.no_overlap)
+                            use_graph=not args.no_graph, overlap=not args.no_overlap, precision=args.dtype)
     # shard sizes of the named 100-node split (reference mnist.py:100-118)
     n_tr, n_va, n_te = reference_shard_sizes(args.split_nodes)
     tx, ty, vx, vy, ex, ey = synthetic_shards(fed.n_local, n_tr, n_va, n_te, spec.num_classes, seed=args.seed,
@@ -157,6 +176,7 @@ def main() -> None:
     if rank == 0:
         sps = samples / elapsed
         steps_per_epoch = -(-n_tr // args.batch_size)
+        base = eager_baseline_samples_per_sec() if args.config is None and args.impl == "hip" else None
         out = {
             "metric": "aggregate client samples/sec (federated rounds, MNIST CNN, 100 nodes per GPU)"
             if args.config is None else f"aggregate client samples/sec (federated rounds, {args.config})",
@@ -168,9 +188,10 @@ def main() -> None:
             "ms_per_step": 1000.0 * elapsed / args.steps,
             "higher_is_better": True,
             "scaling": args.scaling,
-            "vs_baseline": (sps / (EAGER_BASELINE_SAMPLES_PER_SEC * world))
-            if EAGER_BASELINE_SAMPLES_PER_SEC and args.config is None else None,
-            "dtype": "bf16" if args.impl == "hip" else "fp32",
+            "vs_baseline": (sps / (base * world)) if base else None,
+            "baseline_source": "profiles/eager_baseline.json (bench.py --impl eager --save-baseline, same box class)"
+            if base else None,
+            "dtype": args.dtype if args.impl == "hip" else "fp32",
             "data": "synthetic",
             "rounds_per_sec": args.steps / elapsed,
             "config": {
@@ -185,6 +206,10 @@ def main() -> None:
             },
         }
         print(json.dumps(out), flush=True)
+        if args.save_baseline and args.impl == "eager" and args.config is None:
+            os.makedirs(os.path.dirname(BASELINE_FILE), exist_ok=True)
+            with open(BASELINE_FILE, "w") as f:
+                json.dump(out, f, indent=1)
     if pg is not None:
         dist.destroy_process_group()
 

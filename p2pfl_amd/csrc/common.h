@@ -13,6 +13,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int WAVE = 64;
 
+// Precision policy of the matrix products (argument `prec` of the launchers):
+//   PREC_F32  - fp32 operands on v_mfma_f32_32x32x2_f32: exact fp32 fma chains, the reference's precision
+//   PREC_BF16 - operands rounded to bf16, fp32 accumulation (16x the matrix-core rate)
+constexpr int PREC_BF16 = 0;
+constexpr int PREC_F32 = 1;
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // 8 fp32 -> 8 bf16 (RNE; hipcc lowers the casts to v_cvt_pk_bf16_f32 on gfx950).

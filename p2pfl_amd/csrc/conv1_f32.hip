@@ -1,23 +1,18 @@
 // Stage-1 convolution (C_in = 1; 5x5 or 7x7, "same" padding, + ReLU + 2x2 max-pool) of the MNIST / FEMNIST
-// CNNs on the gfx950 matrix cores, client-batched.
+// CNNs in full fp32 on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chains), client-batched.
+// The reference-precision siblings of the bf16 kernels in conv1.hip; same decomposition, but an fp32 MFMA takes
+// ONE float of each operand per lane (lane l: A[row l & 31][k = l >> 5], B[k = l >> 5][col l & 31]), so every
+// fragment is a ds_read_b32 at (per-lane base + immediate) and the k order is free to choose:
 //
-// K = 25 / 49 taps is thin for a GEMM, but with the taps laid out as k = ky*8 + kx (kx padded to 8) an
-// MFMA operand fragment (8 consecutive k) is simply 8 consecutive pixels of one image row: the padded
-// image of a sample sits in LDS as bf16 and every fragment is ONE ds_read_b128 at a pixel address
-// (gfx950 LDS reads need no alignment), no im2col, no gather.
-//
-//   forward   C_q[f][window] = sum_k W[f][k] X_q[window][k]   one wave = one image, 7 tiles of 32 pool windows, one
-//             accumulator per window position q: a lane ends up with the four pixels of ITS window for 16
-//             filters, so max / arg-max / ReLU are in-lane compares and every store instruction writes 32
-//             consecutive pooled outputs (128 B) of a filter. (A first version that put the four pixels of
-//             a window into four lanes spent 8x the VALU work on DPP exchanges and stored 32-byte pieces:
-//             0.93 ms vs 1.2 ms for the VALU kernel it replaced, 1000 FEMNIST clients.)
-//   weight    dW[f][k] = sum_{q, window} G_q[f][window] X_q[window][k]     the pooled gradient is routed to the
-//   gradient  arg-max pixel by masking with the code (4 masks of ONE operand read); the image is kept
-//             de-interleaved by column parity so that 8 consecutive windows of a window row are 8 consecutive
-//             bf16; tap 63 is an all-ones column whose product is the bias gradient. A block streams the
-//             images of a client through double-buffered LDS with coalesced loads (gradient, codes, pixels);
-//             its four waves split the 14 window rows; fp32 atomics of the per-wave [32 x 64] partials.
+//   forward   C_q[f][window] = sum_k W[f][k] X_q[window][k]   one wave = one image in a private LDS copy, 7 tiles of
+//             32 pool windows, one accumulator per window position q. k pairs are (ky, kx) | (ky + 1, kx): the lane
+//             half selects the filter row, folded into the base address; filter taps live in registers.
+//   weight    dW[f][n] = sum_{q, window} G_q[f][window] X_q[window][n]   n = tap (ky * KS + kx), n = KS*KS is the
+//   gradient  all-ones column (bias gradient); k pairs are windows (px, px + 7) of one window row, so a lane half
+//             owns 7 consecutive windows and nothing is padded; the pooled gradient is routed to the arg-max
+//             pixel by comparing the code with q while the operand is built. Image de-interleaved by column
+//             parity so that the 7 windows are 7 consecutive floats. Blocks stream the images of a client through
+//             double-buffered LDS, the four waves split the 14 window rows, fp32 atomics of the per-wave partials.
 //
 // Reference layers: fedstellar/learning/pytorch/mnist/models/cnn.py:134-138,151-152 (5x5),
 // fedstellar/learning/pytorch/femnist/models/cnn.py:136,147 (7x7).
@@ -35,28 +30,6 @@ __device__ __forceinline__ int mfma_row(int reg, int lane) {
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte access
 
-__device__ __forceinline__ bf16x8 lds_read8(const __bf16* p) {
-    bf16x8 v;
-    __builtin_memcpy(&v, p, 16);   // ds_read_b128 at a 2-byte aligned address
-    return v;
-}
-
-// A fragments of the filter bank: lane (f = lane & 31, h = lane >> 5), k-step kk covers taps ky = 2kk + h, kx = 0..7
-template <int KS, int NKK>
-__device__ __forceinline__ void load_filter_frags(const float* w, int F, bf16x8 (&wf)[NKK]) {
-    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) {
-        const int ky = 2 * kk + h;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            wf[kk][j] = (__bf16)((r < F && ky < KS && j < KS) ? w[r * KS * KS + ky * KS + j] : 0.f);
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// forward
-// ---------------------------------------------------------------------------------------
 struct Conv1Args {
     const float* data; long data_cs;   // [K][n_samples][784]
     const int* sidx;   long sidx_cs;   // [K][B] sample indices (or null: identity)
@@ -68,21 +41,21 @@ struct Conv1Args {
 };
 
 template <int KS>
-__global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args a) {
+__global__ __launch_bounds__(256) void conv1_fwd_f32_kernel(Conv1Args a) {
     constexpr int PAD = KS / 2;
-    constexpr int NKK = (KS * 8 + 15) / 16;     // k-steps of 16 taps (two filter rows each): 3 / 4
+    constexpr int NKK = (KS + 1) / 2;           // filter-row pairs: 3 / 4
     constexpr int ROWS = IMG + 2 * NKK;         // last pixel row 27 + last tap row 2 NKK - 1
-    constexpr int LW = 36;                      // last pixel column 27 + kx 7 = 34
+    constexpr int LW = 36;                      // last pixel column 27 + kx 6 = 33
     constexpr int NPX = IMG * IMG / 4;          // float4 per image
     constexpr int OT_LD = 40, CT_LD = 48;       // output patch rows: 32 windows + pad (bank spread / 16-B rows)
     // one private image + output patch per wave: no workgroup barrier anywhere in this kernel
-    __shared__ __attribute__((aligned(16))) __bf16 img[4][ROWS * LW + 8];
+    __shared__ __attribute__((aligned(16))) float img[4][ROWS * LW];
     __shared__ __attribute__((aligned(16))) float otile[4][32 * OT_LD];
     __shared__ __attribute__((aligned(16))) uint8_t ctile[4][32 * CT_LD];
 
     const int c = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
-    __bf16* my = img[wave];
+    float* my = img[wave];
     float* ot = otile[wave];
     uint8_t* ct = ctile[wave];
     const int ipw = a.ipw;                                   // images per wave (weights / bias loaded once)
@@ -100,9 +73,18 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args a) {
         for (int i = 0; i < 4; ++i)
             if (lane + 64 * i < NPX) px[i] = src[lane + 64 * i];
     }
-    for (int i = lane; i < (ROWS * LW + 8) / 2; i += 64) reinterpret_cast<uint32_t*>(my)[i] = 0u;   // zero border, once
-    bf16x8 wf[NKK];
-    load_filter_frags<KS, NKK>(a.w + c * a.w_cs, a.F, wf);
+    for (int i = lane; i < ROWS * LW; i += 64) my[i] = 0.f;   // zero border, once
+    // A operand: filter taps of filter r, row 2 kk + h
+    float wf[NKK][KS];
+    {
+        const float* w = a.w + c * a.w_cs;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            const int ky = 2 * kk + h;
+#pragma unroll
+            for (int j = 0; j < KS; ++j) wf[kk][j] = (r < a.F && ky < KS) ? w[r * KS * KS + ky * KS + j] : 0.f;
+        }
+    }
     float bv[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -116,10 +98,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args a) {
             const int o = lane + 64 * i;
             if (o < NPX) {
                 const int y = o / (IMG / 4), x = 4 * (o - y * (IMG / 4));
-                bf16x4 q;
+                float* dst = my + (y + PAD) * LW + x + PAD;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) q[j] = (__bf16)px[i][j];
-                __builtin_memcpy(my + (y + PAD) * LW + x + PAD, &q, 8);
+                for (int j = 0; j < 4; ++j) dst[j] = px[i][j];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -143,12 +124,14 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args a) {
                 for (int d = 0; d < 2; ++d)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
-                const __bf16* p = my + (2 * py + half + h) * LW + 2 * pxx;
+                const float* p = my + (2 * py + half + h) * LW + 2 * pxx;
 #pragma unroll
                 for (int kk = 0; kk < NKK; ++kk)
 #pragma unroll
-                    for (int d = 0; d < 2; ++d)
-                        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk], lds_read8(p + d + 2 * kk * LW), acc[d], 0, 0, 0);
+                    for (int j = 0; j < KS; ++j)
+#pragma unroll
+                        for (int d = 0; d < 2; ++d)
+                            acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[kk][j], p[2 * kk * LW + d + j], acc[d], 0, 0, 0);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     if (half == 0) { best[e] = acc[0][e]; qi[e] = 0; }
@@ -157,8 +140,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args a) {
                 }
             }
             // bias + ReLU, then the tile (32 windows x 32 filters) goes through a per-wave LDS patch so that the
-            // stores are 16 bytes per lane in address order: 5 store instructions per tile instead of 32
-            // (measured: the 4-byte / 1-byte per lane stores cost as much as all the arithmetic).
+            // stores are 16 bytes per lane in address order
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float v = best[e] + bv[e]; int q = qi[e];
@@ -176,12 +158,12 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args a) {
                         *reinterpret_cast<const f32x4*>(ot + f * OT_LD + 4 * j);
             }
             {
-                const int f = lane >> 1, half = lane & 1, w0 = tile * 32 + 16 * half;
+                const int f = lane >> 1, hf = lane & 1, w0 = tile * 32 + 16 * hf;
                 uint8_t* dst = code + (size_t)f * CELLS1 + w0;
                 if (f < a.F && w0 + 16 <= CELLS1)
-                    *reinterpret_cast<u32x4_a4*>(dst) = *reinterpret_cast<const u32x4_a4*>(ct + f * CT_LD + 16 * half);
+                    *reinterpret_cast<u32x4_a4*>(dst) = *reinterpret_cast<const u32x4_a4*>(ct + f * CT_LD + 16 * hf);
                 else if (f < a.F && w0 < CELLS1)          // last tile: windows 192..195
-                    *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(ct + f * CT_LD + 16 * half);
+                    *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(ct + f * CT_LD + 16 * hf);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
@@ -201,25 +183,24 @@ struct Conv1WgradArgs {
     int B, F;
 };
 
-constexpr int WG_ROWS = 36;     // last row 2*13 + 1 + tap row 7 = 34
-constexpr int WG_HW = 24;       // half-row: last index 8 + 7 + (8 >> 1) = 19
-constexpr int WG_IMG = WG_ROWS * WG_HW + 8;
-constexpr int WG_G = 32 * CELLS1 + 8;
+constexpr int WG_ROWS = 36;     // last row 2*13 + 1 + tap row 6 = 33
+constexpr int WG_HW = 24;       // half-row: last index 13 + (1 + 6 >> 1) = 16
+constexpr int WG_IMG = WG_ROWS * WG_HW;
+constexpr int WG_GS = CELLS1 + 1;      // odd filter stride of the gradient rows: lanes = filters hit 32 banks
+constexpr int WG_CS = CELLS1 + 4;      // code rows (bytes): 50 dwords - 2-way at worst, words stay aligned
 
-struct Conv1WgradSmem {
-    __bf16 img[2][WG_IMG];      // [parity][row][i] = padded pixel (row, 2 i + parity)
-    __bf16 g[WG_G];             // pooled gradient [f][196]
-    uint8_t code[WG_G];         // arg-max codes   [f][196]
+struct Conv1WgradSmemF {
+    float img[2][WG_IMG];       // [parity][row][i] = padded pixel (row, 2 i + parity)
+    float g[32 * WG_GS];        // pooled gradient [f][196]
+    uint8_t code[32 * WG_CS];   // arg-max codes   [f][196]
 };
 
-// registers of one image in flight (coalesced global loads; 256 threads)
 template <int KS>
-struct Conv1WgradStage {
+struct Conv1WgradStageF {
     static constexpr int PAD = KS / 2;
     static constexpr int NG = (32 * CELLS1 / 4 + 255) / 256;   // float4 of the gradient per thread: 7
-    static constexpr int NC = (32 * CELLS1 / 4 + 255) / 256;   // code words per thread: 7
     static constexpr int NP = (2 * WG_IMG + 255) / 256;        // staged pixels per thread: 7
-    f32x4 g[NG]; uint32_t c[NC]; float px[NP];
+    f32x4 g[NG]; uint32_t c[NG]; float px[NP];
 
     __device__ __forceinline__ void load(const Conv1WgradArgs& a, int cl, int b) {
         const int n4 = a.F * CELLS1 / 4;
@@ -237,54 +218,59 @@ struct Conv1WgradStage {
             const int o2 = threadIdx.x + i * 256;
             const int par = o2 / WG_IMG, o = o2 - par * WG_IMG;
             const int y = o / WG_HW - PAD, x = 2 * (o % WG_HW) + par - PAD;
-            px[i] = (o2 < 2 * WG_IMG && o < WG_ROWS * WG_HW && y >= 0 && y < IMG && x >= 0 && x < IMG) ? src[y * IMG + x] : 0.f;
+            px[i] = (o2 < 2 * WG_IMG && y >= 0 && y < IMG && x >= 0 && x < IMG) ? src[y * IMG + x] : 0.f;
         }
     }
-    __device__ __forceinline__ void store(const Conv1WgradArgs& a, Conv1WgradSmem& sm) const {
+    __device__ __forceinline__ void store(const Conv1WgradArgs& a, Conv1WgradSmemF& sm) const {
         const int n4 = a.F * CELLS1 / 4;
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const int o = threadIdx.x + i * 256;
             if (o < n4) {
-                bf16x4 q;
+                const int f = o / (CELLS1 / 4), j = o - f * (CELLS1 / 4);     // 49 float4 per filter row
+                float* gd = sm.g + f * WG_GS + 4 * j;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) q[j] = (__bf16)g[i][j];
-                *reinterpret_cast<bf16x4*>(sm.g + 4 * o) = q;
-                *reinterpret_cast<uint32_t*>(sm.code + 4 * o) = c[i];
+                for (int e = 0; e < 4; ++e) gd[e] = g[i][e];
+                *reinterpret_cast<uint32_t*>(sm.code + f * WG_CS + 4 * j) = c[i];
             }
         }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int o2 = threadIdx.x + i * 256;
-            if (o2 < 2 * WG_IMG) (&sm.img[0][0])[o2] = (__bf16)px[i];
+            if (o2 < 2 * WG_IMG) (&sm.img[0][0])[o2] = px[i];
         }
     }
 };
 
 template <int KS>
-__global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1WgradArgs a) {
-    __shared__ __attribute__((aligned(16))) Conv1WgradSmem smem[2];
+__global__ __launch_bounds__(256) void conv1_wgrad_f32_kernel(Conv1WgradArgs a) {
+    constexpr int T = KS * KS;
+    constexpr int NJN = (T + 1 + 31) / 32;       // column tiles of (taps + bias): 1 / 2
+    __shared__ __attribute__((aligned(16))) Conv1WgradSmemF smem[2];
 
     const int c = blockIdx.z, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
-    // rows of filters >= F (and the read-ahead pad) stay "no gradient" for the whole kernel
-    for (int i = threadIdx.x; i < 2 * WG_G; i += 256) {
-        Conv1WgradSmem& s = smem[i / WG_G];
-        const int o = i % WG_G;
-        s.g[o] = (__bf16)0.f;
-        s.code[o] = 4;
-    }
+    // rows of filters >= F stay "no gradient" for the whole kernel
+    for (int i = threadIdx.x; i < 2 * 32 * WG_GS; i += 256) smem[i / (32 * WG_GS)].g[i % (32 * WG_GS)] = 0.f;
+    for (int i = threadIdx.x; i < 2 * 32 * WG_CS; i += 256) smem[i / (32 * WG_CS)].code[i % (32 * WG_CS)] = 4;
     __syncthreads();
-    f32x16 acc[2];
+    f32x16 acc[NJN];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-    bf16x8 ones;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.f;
 
-    Conv1WgradStage<KS> st;
+    // B operand roles: column n = jn * 32 + r is tap (ky, kx) = (n / KS, n % KS), n == T the ones column
+    int ky[NJN], kx[NJN]; bool is_tap[NJN], is_one[NJN];
+#pragma unroll
+    for (int jn = 0; jn < NJN; ++jn) {
+        const int n = jn * 32 + r;
+        is_tap[jn] = n < T; is_one[jn] = n == T;
+        ky[jn] = is_tap[jn] ? n / KS : 0;
+        kx[jn] = is_tap[jn] ? n % KS : 0;
+    }
+
+    Conv1WgradStageF<KS> st;
     int b = blockIdx.x;
     if (b < a.B) { st.load(a, c, b); st.store(a, smem[0]); }
     __syncthreads();
@@ -292,29 +278,31 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1WgradArgs a) {
     for (; b < a.B; b += gridDim.x) {
         const bool has_next = b + (int)gridDim.x < a.B;
         if (has_next) st.load(a, c, b + gridDim.x);          // global loads fly while this image is consumed
-        const Conv1WgradSmem& sm = smem[cur];
+        const Conv1WgradSmemF& sm = smem[cur];
         for (int py = wave; py < P1; py += 4) {
-            // pooled gradient + codes of 8 windows (px = 8h .. 8h+7; px >= 14 is padding) of filter r
-            const int o = r * CELLS1 + py * P1 + 8 * h;
-            const bf16x8 gv = lds_read8(sm.g + o);
-            uint8_t cv[8];
-            __builtin_memcpy(cv, sm.code + o, 8);
+            // pooled gradient + codes of the 7 windows px = 7h .. 7h+6 of filter r
+            const float* gr = sm.g + r * WG_GS + py * P1 + 7 * h;
+            const uint8_t* cr = sm.code + r * WG_CS + py * P1 + 7 * h;
+            float gv[7]; int cv[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) { gv[j] = gr[j]; cv[j] = cr[j]; }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                bf16x8 af;
+                const float* bp[NJN];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const bool on = cv[j] == q && (j < 6 || h == 0);
-                    af[j] = on ? gv[j] : (__bf16)0.f;
+                for (int jn = 0; jn < NJN; ++jn) {
+                    // pixel of window px for tap (ky, kx): (2py + dy + ky, 2px + dx + kx)
+                    const int v = (q & 1) + kx[jn];
+                    bp[jn] = sm.img[v & 1] + (2 * py + (q >> 1) + ky[jn]) * WG_HW + 7 * h + (v >> 1);
                 }
 #pragma unroll
-                for (int jn = 0; jn < 2; ++jn) {
-                    // B rows: taps n = jn*32 + r = ky*8 + kx; pixel of window px: (2py + dy + ky, 2px + dx + kx)
-                    const int n = jn * 32 + r, ky = n >> 3, kx = n & 7;
-                    const int v = (q & 1) + kx;
-                    const __bf16* p = sm.img[v & 1] + (2 * py + (q >> 1) + ky) * WG_HW + 8 * h + (v >> 1);
-                    const bf16x8 bfr = (n == 63) ? ones : lds_read8(p);
-                    acc[jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[jn], 0, 0, 0);
+                for (int j = 0; j < 7; ++j) {
+                    const float av = cv[j] == q ? gv[j] : 0.f;
+#pragma unroll
+                    for (int jn = 0; jn < NJN; ++jn) {
+                        const float bvv = is_tap[jn] ? bp[jn][j] : (is_one[jn] ? 1.f : 0.f);
+                        acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvv, acc[jn], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -322,18 +310,18 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1WgradArgs a) {
         __syncthreads();
         cur ^= 1;
     }
-    // acc[jn][e] = partial dW[f = mfma_row(e)][tap n = jn*32 + r] of this wave's window rows
+    // acc[jn][e] = partial dW[f = mfma_row(e)][column n = jn*32 + r] of this wave's window rows
     float* dw = a.dw + c * a.dw_cs;
     float* db = a.db + c * a.db_cs;
 #pragma unroll
-    for (int jn = 0; jn < 2; ++jn) {
-        const int n = jn * 32 + r, ky = n >> 3, kx = n & 7;
+    for (int jn = 0; jn < NJN; ++jn) {
+        const int n = jn * 32 + r;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int fo = mfma_row(e, lane);
             if (fo >= a.F) continue;
-            if (n == 63) atomicAdd(db + fo, acc[jn][e]);
-            else if (ky < KS && kx < KS) atomicAdd(dw + fo * KS * KS + ky * KS + kx, acc[jn][e]);
+            if (n == T) atomicAdd(db + fo, acc[jn][e]);
+            else if (n < T) atomicAdd(dw + fo * T + n, acc[jn][e]);
         }
     }
 }
@@ -342,46 +330,37 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace
 
-P2PFL_API int p2pfl_conv1_fwd(const float* data, long data_cs, const int* sidx, long sidx_cs,
-                              const float* w, long w_cs, const float* bias, long b_cs, float* a1,
-                              long a_cs, uint8_t* code, long c_cs, int K, int B, int F, int KS, int prec,
-                              hipStream_t stream) {
-    if (prec == PREC_F32)
-        return conv1_fwd_f32(data, data_cs, sidx, sidx_cs, w, w_cs, bias, b_cs, a1, a_cs, code, c_cs, K, B, F, KS, stream);
+int conv1_fwd_f32(const float* data, long data_cs, const int* sidx, long sidx_cs, const float* w, long w_cs,
+                  const float* bias, long b_cs, float* a1, long a_cs, uint8_t* code, long c_cs, int K, int B, int F,
+                  int KS, hipStream_t stream) {
     if (K <= 0 || B <= 0 || F <= 0 || F > 32) return -1;
     if (((uintptr_t)data & 15) || (data_cs & 3)) return -2;      // float4 loads of whole 784-pixel images
     if (((uintptr_t)a1 & 15) || (a_cs & 3) || ((uintptr_t)code & 3) || (c_cs & 3)) return -2;   // 16-byte output pieces
-    // images per wave: amortise the filter / bias loads once there are >= ~2 waves per SIMD anyway
     int ipw = (int)(((long)K * B / 4) / 2048);
     if (ipw < 1) ipw = 1;
     if (ipw > 8) ipw = 8;
     Conv1Args a{data, data_cs, sidx, sidx_cs, w, w_cs, bias, b_cs, a1, a_cs, code, c_cs, B, F, ipw};
     dim3 grid(cdiv(B, 4 * ipw), K);
-    if (KS == 5) hipLaunchKernelGGL(conv1_fwd_kernel<5>, grid, dim3(256), 0, stream, a);
-    else if (KS == 7) hipLaunchKernelGGL(conv1_fwd_kernel<7>, grid, dim3(256), 0, stream, a);
+    if (KS == 5) hipLaunchKernelGGL(conv1_fwd_f32_kernel<5>, grid, dim3(256), 0, stream, a);
+    else if (KS == 7) hipLaunchKernelGGL(conv1_fwd_f32_kernel<7>, grid, dim3(256), 0, stream, a);
     else return -3;
     P2PFL_RETURN_LAST_ERROR();
 }
 
-P2PFL_API int p2pfl_conv1_wgrad(const float* g, long g_cs, const uint8_t* code, long c_cs,
-                                const float* data, long data_cs, const int* sidx, long sidx_cs,
-                                float* dw, long dw_cs, float* db, long db_cs, int K, int B, int F,
-                                int KS, int prec, hipStream_t stream) {
-    if (prec == PREC_F32)
-        return conv1_wgrad_f32(g, g_cs, code, c_cs, data, data_cs, sidx, sidx_cs, dw, dw_cs, db, db_cs, K, B, F, KS,
-                               stream);
+int conv1_wgrad_f32(const float* g, long g_cs, const uint8_t* code, long c_cs, const float* data, long data_cs,
+                    const int* sidx, long sidx_cs, float* dw, long dw_cs, float* db, long db_cs, int K, int B, int F,
+                    int KS, hipStream_t stream) {
     if (K <= 0 || B <= 0 || F <= 0 || F > 32) return -1;
     // dw/db are accumulated with atomics: the caller zeroes them first (p2pfl_zero_rows).
-    // float4 / word loads of the pooled gradient and the codes of an image
     if (((uintptr_t)g & 15) || (g_cs & 3) || ((uintptr_t)code & 3) || (c_cs & 3)) return -2;
-    // blocks per client: about 1.5 per CU over the launch, at most one per image (more blocks = more atomics)
-    int splits = cdiv(384, K);     // measured (7x7; 10 / 50 / 100 clients): target 256: 49 / 63 / 107 us, 384: 63 / 63 / 91, 512: 63 / 67 / 87, 768: 63 / 88 / 110, 1536: 64 / 124 / 140
+    // matrix-pipe-bound: about two blocks per CU over the launch, at most one per image
+    int splits = cdiv(512, K);
     if (splits > B) splits = B;
     if (splits < 1) splits = 1;
     Conv1WgradArgs a{g, g_cs, code, c_cs, data, data_cs, sidx, sidx_cs, dw, dw_cs, db, db_cs, B, F};
     dim3 grid(splits, 1, K);
-    if (KS == 5) hipLaunchKernelGGL(conv1_wgrad_kernel<5>, grid, dim3(256), 0, stream, a);
-    else if (KS == 7) hipLaunchKernelGGL(conv1_wgrad_kernel<7>, grid, dim3(256), 0, stream, a);
+    if (KS == 5) hipLaunchKernelGGL(conv1_wgrad_f32_kernel<5>, grid, dim3(256), 0, stream, a);
+    else if (KS == 7) hipLaunchKernelGGL(conv1_wgrad_f32_kernel<7>, grid, dim3(256), 0, stream, a);
     else return -3;
     P2PFL_RETURN_LAST_ERROR();
 }

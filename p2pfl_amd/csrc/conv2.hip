@@ -21,7 +21,7 @@
 //
 // Reference layers: fedstellar/learning/pytorch/mnist/models/cnn.py:138-142,152-154 and
 // fedstellar/learning/pytorch/femnist/models/cnn.py:137-139,147-148.
-#include "common.h"
+#include "conv_f32.h"
 
 namespace {
 
@@ -562,9 +562,11 @@ __global__ __launch_bounds__(256) void conv2_wgrad_reduce_kernel(WgradArgs a) {
 // C ABI
 // ---------------------------------------------------------------------------------------
 // wp: per client 2 * KS*KS * 64 * 32 bf16 (forward copy, then mirrored data-gradient copy)
+// (prec == PREC_F32: floats instead of bf16, forward copy [t][ci][co] + data-gradient copy [t'][co][ci]: conv2_f32.hip)
 P2PFL_API int p2pfl_conv2_prep(const float* w, long w_cs, void* wp, long wp_cs, int K, int CIN_, int COUT_,
-                               int KS, hipStream_t stream) {
+                               int KS, int prec, hipStream_t stream) {
     if (K <= 0 || CIN_ != CIN || COUT_ != COUT) return -1;
+    if (prec == PREC_F32) return conv2_prep_f32(w, w_cs, (float*)wp, wp_cs, K, KS, stream);
     if (wp_cs < 2L * KS * KS * COUT * CIN || (wp_cs & 7) || ((uintptr_t)wp & 15)) return -2;
     dim3 grid(cdiv(COUT * CIN * KS * KS, 256 * 4), K);
     if (KS == 5) hipLaunchKernelGGL(conv2_prep_kernel<5>, grid, dim3(256), 0, stream, w, w_cs, (__bf16*)wp, wp_cs);
@@ -575,8 +577,10 @@ P2PFL_API int p2pfl_conv2_prep(const float* w, long w_cs, void* wp, long wp_cs, 
 
 P2PFL_API int p2pfl_conv2_fwd(const float* a1, long a1_cs, const void* wp, long wp_cs, const float* bias,
                               long b_cs, float* a2, long a2_cs, uint8_t* code, long c_cs, int K, int B,
-                              int CIN_, int COUT_, int KS, hipStream_t stream) {
+                              int CIN_, int COUT_, int KS, int prec, hipStream_t stream) {
     if (K <= 0 || B <= 0 || CIN_ != CIN || COUT_ != COUT) return -1;
+    if (prec == PREC_F32)
+        return conv2_fwd_f32(a1, a1_cs, (const float*)wp, wp_cs, bias, b_cs, a2, a2_cs, code, c_cs, K, B, KS, stream);
     if ((wp_cs & 7) || ((uintptr_t)wp & 15)) return -2;
     if (((uintptr_t)a2 & 15) || (a2_cs & 3) || ((uintptr_t)code & 15) || (c_cs & 15)) return -2;   // 16-byte block stores
     FwdArgs a{a1, a1_cs, (const __bf16*)wp, wp_cs, bias, b_cs, a2, a2_cs, code, c_cs, K, B};
@@ -589,8 +593,10 @@ P2PFL_API int p2pfl_conv2_fwd(const float* a1, long a1_cs, const void* wp, long 
 
 P2PFL_API int p2pfl_conv2_dgrad(const float* g, long g_cs, const uint8_t* code, long c_cs, const void* wp,
                                 long wp_cs, float* da1, long da1_cs, int K, int B, int CIN_, int COUT_,
-                                int KS, hipStream_t stream) {
+                                int KS, int prec, hipStream_t stream) {
     if (K <= 0 || B <= 0 || CIN_ != CIN || COUT_ != COUT) return -1;
+    if (prec == PREC_F32)
+        return conv2_dgrad_f32(g, g_cs, code, c_cs, (const float*)wp, wp_cs, da1, da1_cs, K, B, KS, stream);
     if ((wp_cs & 7) || ((uintptr_t)wp & 15) || (da1_cs & 3) || ((uintptr_t)da1 & 15)) return -2;
     DgradArgs a{g, g_cs, code, c_cs, (const __bf16*)wp, wp_cs, da1, da1_cs, K, B};
     dim3 grid(cdiv(K, 8) * 8 * B);
@@ -642,8 +648,9 @@ static void wgrad_split(int K, int B, int KS, int cus, int& np, int& ns) {
 }
 
 // floats of scratch p2pfl_conv2_wgrad wants for this problem (0: none)
-P2PFL_API long p2pfl_conv2_wgrad_scratch(int K, int B, int KS) {
+P2PFL_API long p2pfl_conv2_wgrad_scratch(int K, int B, int KS, int prec) {
     if (K <= 0 || B <= 0) return 0;
+    if (prec == PREC_F32) return conv2_wgrad_f32_scratch(K, B, KS);
     int np, ns;
     wgrad_split(K, B, KS, num_cus(), np, ns);
     return ns > 1 ? (long)K * ns * (KS * KS * COUT * CIN + COUT) : 0;
@@ -651,9 +658,12 @@ P2PFL_API long p2pfl_conv2_wgrad_scratch(int K, int B, int KS) {
 
 P2PFL_API int p2pfl_conv2_wgrad(const float* g, long g_cs, const uint8_t* code, long c_cs, const float* a1,
                                 long a1_cs, float* dw, long dw_cs, float* db, long db_cs, float* scratch,
-                                long scratch_floats, int K, int B, int CIN_, int COUT_, int KS,
+                                long scratch_floats, int K, int B, int CIN_, int COUT_, int KS, int prec,
                                 hipStream_t stream) {
     if (K <= 0 || B <= 0 || CIN_ != CIN || COUT_ != COUT) return -1;
+    if (prec == PREC_F32)
+        return conv2_wgrad_f32(g, g_cs, code, c_cs, a1, a1_cs, dw, dw_cs, db, db_cs, scratch, scratch_floats, K, B, KS,
+                               stream);
     int np, ns;
     wgrad_split(K, B, KS, num_cus(), np, ns);
     if (scratch == nullptr || scratch_floats < (long)K * ns * (KS * KS * COUT * CIN + COUT)) ns = 1;

@@ -1,0 +1,623 @@
+// Stage-2 convolution (C_in = 32 -> C_out = 64, 5x5 or 3x3 "same", + ReLU + 2x2 max-pool) of the MNIST /
+// FEMNIST CNNs in full fp32 on the gfx950 matrix cores: forward, data gradient, weight gradient.
+//
+// This is the reference-precision path (the reference trains 32-bit: fedstellar/learning/pytorch/
+// lightninglearner.py:182-193): operands are never rounded, every product runs on
+// v_mfma_f32_32x32x2_f32, whose result is bit-for-bit an fp32 fma chain.
+//
+// Design: "resident image, one dword per lane". The fp32 MFMA takes ONE float of A and ONE float of B per
+// lane (lane l: A[row l & 31][k = l >> 5], B[k = l >> 5][col l & 31]), so operand fragments are plain
+// ds_read_b32 and the only layout question is the bank pattern of 32 consecutive lanes:
+//   * images are kept CHANNEL-MAJOR in LDS, [channel][padded pixel], with an ODD channel stride
+//     (18 x 18 + 1 = 325 / 16 x 16 + 1 = 257 floats): when the lane index is the channel (weight gradient),
+//     32 lanes hit 32 different banks; when the lane index is the pixel (forward / data gradient), lanes walk
+//     along image rows. Channel-major is also the layout of the activations in memory (NCHW), so staging is
+//     a straight copy of 196-float rows - no transposition anywhere, unlike the bf16 kernels (conv2.hip),
+//     which need channel-last images for their 8-element fragments.
+//   * the k index of a product is (channel pair | pixel pair); the lane half h picks the element of the
+//     pair, folded into the per-lane base address, so every read in the unrolled loops is base + immediate.
+//   * a filter tap is a constant address offset on the image (never an im2col matrix); per tap the
+//     [k][n] weight slice (8 KB of a tap-major fp32 copy made once per step by conv2_prep_f32) is
+//     double-buffered through LDS.
+// The fp32 MFMA issues at 1/16 of the bf16 rate (64 cycles per 32x32x2), so unlike their bf16 siblings these
+// kernels are matrix-pipe-bound: one ds_read_b32 (2 LDS cycles) per 64-cycle MFMA, and what matters is that
+// every SIMD of every CU always has an MFMA to issue (work units dealt evenly to the waves).
+//
+// Reference layers: fedstellar/learning/pytorch/mnist/models/cnn.py:138-142,152-154 and
+// fedstellar/learning/pytorch/femnist/models/cnn.py:137-139,147-148.
+#include "conv_f32.h"
+
+namespace {
+
+constexpr int P1 = 14, P2 = 7, CELLS1 = 196, CELLS2 = 49;
+constexpr int CIN = 32, COUT = 64;
+
+__host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+__device__ __forceinline__ int mfma_row_(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+template <int KS>
+struct GeoF {
+    static constexpr int PAD = KS / 2;
+    static constexpr int IW = P1 + 2 * PAD;          // padded image width (18 / 16)
+    static constexpr int T = KS * KS;
+    static constexpr int CS = (IW * IW) | 1;         // odd channel stride in floats (325 / 257)
+};
+
+// block id -> (client, sub-block) with all sub-blocks of a client on one XCD (ids round-robin over 8 XCDs)
+__device__ __forceinline__ bool xcd_map(int per_client, int K, int& c, int& sub) {
+    const int i = blockIdx.x;
+    const int xcd = i & 7, j = i >> 3;
+    c = (j / per_client) * 8 + xcd;
+    sub = j % per_client;
+    return c < K;
+}
+
+// ---------------------------------------------------------------------------------------
+// weight prep: W[n][c][t] -> Wf[t][c][n] (forward B operand, lane = n) and Wd[t'][n][c] (data-gradient
+// B operand, lane = c, t' = mirrored tap)
+// ---------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256) void conv2_prep_f32_kernel(const float* w, long w_cs, float* wp, long wp_cs) {
+    constexpr int T = KS * KS;
+    const int c = blockIdx.y;
+    const float* src = w + c * w_cs;
+    float* wf = wp + c * wp_cs;
+    float* wd = wf + T * COUT * CIN;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < COUT * CIN * T; o += gridDim.x * 256) {
+        {   // wf[(t * CIN + ci) * COUT + n]
+            const int n = o % COUT, tc = o / COUT;
+            const int ci = tc % CIN, t = tc / CIN;
+            wf[o] = src[(n * CIN + ci) * T + t];
+        }
+        {   // wd[((T - 1 - t) * COUT + n) * CIN + ci]
+            const int ci = o % CIN, tn = o / CIN;
+            const int n = tn % COUT, t = T - 1 - tn / COUT;
+            wd[o] = src[(n * CIN + ci) * T + t];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------
+struct FwdArgs {
+    const float* a1;   long a1_cs;     // [K][B][32][196]
+    const float* wp;   long wp_cs;     // prepared weights
+    const float* bias; long b_cs;      // [K][64]
+    float* a2;         long a2_cs;     // [K][B][64][49]
+    uint8_t* code;     long c_cs;
+    int K, B;
+};
+
+// 2 samples per block: M = 98 pool windows x 4 pixels (pool-ordered: the four rows of a window are four
+// consecutive accumulator registers of one lane -> bias + ReLU + max-pool + arg-max code in registers) = 13 row
+// tiles, x 2 column halves = 26 work units dealt 7 / 7 / 6 / 6 to the four waves (wave & 1 = its column half).
+template <int KS>
+__global__ __launch_bounds__(256) void conv2_fwd_f32_kernel(FwdArgs a) {
+    using G = GeoF<KS>;
+    constexpr int S = 2;
+    constexpr int NWIN = S * CELLS2;           // 98
+    constexpr int NTILE = (NWIN + 7) / 8;      // 13
+    constexpr int MU = (NTILE + 1) / 2;        // row tiles per wave: 7 (even tiles) or 6 (odd tiles)
+    constexpr int XN = S * CIN * G::CS;
+    __shared__ __attribute__((aligned(16))) float ximg[(XN + 3) / 4 * 4];
+    __shared__ __attribute__((aligned(16))) float wbuf[2][CIN * COUT];
+
+    int c, sub;
+    if (!xcd_map(cdiv(a.B, S), a.K, c, sub)) return;
+    const int b0 = sub * S;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    for (int i = tid; i < (XN + 3) / 4; i += 256)
+        reinterpret_cast<f32x4*>(ximg)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* wf = a.wp + c * a.wp_cs;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        reinterpret_cast<f32x4*>(wbuf[0])[tid + 256 * u] = reinterpret_cast<const f32x4*>(wf)[tid + 256 * u];
+    __syncthreads();
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.a1 + c * a.a1_cs + (size_t)b0 * CIN * CELLS1);
+        const int nval = min(S, a.B - b0) * CIN * (CELLS1 / 4);
+        for (int i = tid; i < nval; i += 256) {
+            const f32x4 v = src[i];
+            const int sc = i / (CELLS1 / 4), j = i - sc * (CELLS1 / 4);
+            float* dst = ximg + sc * G::CS + G::PAD * G::IW + G::PAD;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int p = 4 * j + e, y = p / P1, x = p - y * P1;
+                dst[y * G::IW + x] = v[e];
+            }
+        }
+    }
+    __syncthreads();
+
+    const int half = wave & 1, tile0 = wave >> 1;
+    const int ntile = (NTILE - tile0 + 1) / 2;
+    int abase[MU];
+#pragma unroll
+    for (int i = 0; i < MU; ++i) {
+        int W = (tile0 + 2 * i) * 8 + (r >> 2);
+        if (W >= NWIN) W = 0;
+        const int q = r & 3, s = W / CELLS2, cell = W % CELLS2;
+        const int y = 2 * (cell / P2) + (q >> 1), x = 2 * (cell % P2) + (q & 1);
+        abase[i] = (s * CIN + h) * G::CS + y * G::IW + x;
+    }
+    f32x16 acc[MU];
+#pragma unroll
+    for (int i = 0; i < MU; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    int ky = 0, kx = 0;
+#pragma unroll 1
+    for (int t = 0; t < G::T; ++t) {
+        f32x4 wnext[2];
+        if (t + 1 < G::T) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                wnext[u] = reinterpret_cast<const f32x4*>(wf + (t + 1) * COUT * CIN)[tid + 256 * u];
+        }
+        const float* wb = wbuf[t & 1] + h * COUT + half * 32 + r;
+        const int toff = ky * G::IW + kx;
+        const float* ap[MU];
+#pragma unroll
+        for (int i = 0; i < MU; ++i) ap[i] = ximg + abase[i] + toff;
+#pragma unroll
+        for (int s = 0; s < CIN / 2; ++s) {
+            const float bv = wb[2 * s * COUT];
+#pragma unroll
+            for (int i = 0; i < MU; ++i)
+                if (i < ntile) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[i][2 * s * G::CS], bv, acc[i], 0, 0, 0);
+        }
+        if (t + 1 < G::T) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) reinterpret_cast<f32x4*>(wbuf[(t + 1) & 1])[tid + 256 * u] = wnext[u];
+        }
+        __syncthreads();
+        if (++kx == KS) { kx = 0; ++ky; }
+    }
+
+    // ---- epilogue: bias + ReLU + 2x2 max-pool + arg-max code from the accumulators; the block's outputs (S samples
+    // x [64][49], one contiguous piece of a2 and of the codes) are assembled in the now idle image buffer and leave
+    // as 16-byte pieces per lane in address order.
+    static_assert(XN * 4 >= S * COUT * CELLS2 * 5, "output staging must fit into the image buffer");
+    float* out_s = ximg;
+    uint8_t* code_s = reinterpret_cast<uint8_t*>(ximg + S * COUT * CELLS2);
+    const int n = half * 32 + r;
+    const float bv = a.bias[c * a.b_cs + n];
+#pragma unroll
+    for (int i = 0; i < MU; ++i) {
+        if (i >= ntile) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int W = (tile0 + 2 * i) * 8 + 2 * g + h;
+            if (W >= NWIN) continue;
+            float best = acc[i][4 * g]; int q = 0;
+            if (acc[i][4 * g + 1] > best) { best = acc[i][4 * g + 1]; q = 1; }
+            if (acc[i][4 * g + 2] > best) { best = acc[i][4 * g + 2]; q = 2; }
+            if (acc[i][4 * g + 3] > best) { best = acc[i][4 * g + 3]; q = 3; }
+            best += bv;
+            if (!(best > 0.f)) { best = 0.f; q = 4; }
+            const int o = ((W / CELLS2) * COUT + n) * CELLS2 + W % CELLS2;     // == the global layout of the block
+            out_s[o] = best;
+            code_s[o] = (uint8_t)q;
+        }
+    }
+    __syncthreads();
+    const int nvalid = min(S, a.B - b0) * COUT * CELLS2;
+    float* a2 = a.a2 + c * a.a2_cs + (size_t)b0 * COUT * CELLS2;
+    uint8_t* code = a.code + c * a.c_cs + (size_t)b0 * COUT * CELLS2;
+    for (int i = tid; i < nvalid / 4; i += 256)
+        reinterpret_cast<f32x4*>(a2)[i] = reinterpret_cast<const f32x4*>(out_s)[i];
+    for (int i = tid; i < nvalid / 16; i += 256)
+        reinterpret_cast<f32x4*>(code)[i] = reinterpret_cast<const f32x4*>(code_s)[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// data gradient: image = pooled gradient routed to the arg-max pixel while staging (only the 25 % of the
+// pre-pool pixels that won their window are ever written; the rest of the zeroed image stays zero),
+// M = natural pixels of one sample (7 row tiles), N = C_in, k = C_out pairs x mirrored taps.
+// ---------------------------------------------------------------------------------------
+struct DgradArgs {
+    const float* g;    long g_cs;      // da2 [K][B][64][49]
+    const uint8_t* code; long c_cs;
+    const float* wp;   long wp_cs;
+    float* da1;        long da1_cs;    // [K][B][32][196]
+    int K, B;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void conv2_dgrad_f32_kernel(DgradArgs a) {
+    using G = GeoF<KS>;
+    constexpr int NTILE = (CELLS1 + 31) / 32;   // 7
+    constexpr int MT = (NTILE + 3) / 4;         // (2,2,2,1)
+    constexpr int GN = COUT * G::CS;
+    __shared__ __attribute__((aligned(16))) float gimg[(GN + 3) / 4 * 4];
+    __shared__ __attribute__((aligned(16))) float wbuf[2][COUT * CIN];
+
+    int c, b;
+    if (!xcd_map(a.B, a.K, c, b)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    for (int i = tid; i < (GN + 3) / 4; i += 256)
+        reinterpret_cast<f32x4*>(gimg)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* wd = a.wp + c * a.wp_cs + G::T * COUT * CIN;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        reinterpret_cast<f32x4*>(wbuf[0])[tid + 256 * u] = reinterpret_cast<const f32x4*>(wd)[tid + 256 * u];
+    __syncthreads();
+    {
+        const float* gsrc = a.g + c * a.g_cs + (size_t)b * COUT * CELLS2;
+        const uint8_t* csrc = a.code + c * a.c_cs + (size_t)b * COUT * CELLS2;
+        for (int task = tid; task < COUT * CELLS2; task += 256) {
+            const int co = task / CELLS2, cell = task - co * CELLS2;
+            const float gv = gsrc[task];
+            const int q = csrc[task];
+            if (q < 4) {
+                const int Y = 2 * (cell / P2) + G::PAD + (q >> 1), X = 2 * (cell % P2) + G::PAD + (q & 1);
+                gimg[co * G::CS + Y * G::IW + X] = gv;
+            }
+        }
+    }
+    __syncthreads();
+
+    const int ntile = (NTILE - wave + 3) / 4;
+    int abase[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int p = (wave + 4 * i) * 32 + r;
+        if (p >= CELLS1) p = 0;
+        abase[i] = h * G::CS + (p / P1) * G::IW + (p % P1);
+    }
+    f32x16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    int ky = 0, kx = 0;   // mirrored tap index: image offset (ky,kx), weights of tap (KS-1-ky, KS-1-kx)
+#pragma unroll 1
+    for (int t = 0; t < G::T; ++t) {
+        f32x4 wnext[2];
+        if (t + 1 < G::T) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                wnext[u] = reinterpret_cast<const f32x4*>(wd + (t + 1) * COUT * CIN)[tid + 256 * u];
+        }
+        const float* wb = wbuf[t & 1] + h * CIN + r;
+        const int toff = ky * G::IW + kx;
+        const float* ap[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) ap[i] = gimg + abase[i] + toff;
+#pragma unroll
+        for (int s = 0; s < COUT / 2; ++s) {
+            const float bv = wb[2 * s * CIN];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                if (i < ntile) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[i][2 * s * G::CS], bv, acc[i], 0, 0, 0);
+        }
+        if (t + 1 < G::T) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) reinterpret_cast<f32x4*>(wbuf[(t + 1) & 1])[tid + 256 * u] = wnext[u];
+        }
+        __syncthreads();
+        if (++kx == KS) { kx = 0; ++ky; }
+    }
+
+    // ---- epilogue: lane = input channel, registers 4g..4g+3 = four consecutive pixels -> float4
+    float* dst = a.da1 + c * a.da1_cs + ((size_t)b * CIN + r) * CELLS1;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        if (i >= ntile) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int p = (wave + 4 * i) * 32 + 8 * g + 4 * h;
+            if (p < CELLS1)
+                *reinterpret_cast<float4*>(dst + p) =
+                    make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// weight gradient:  dW[n][c][t] = sum_{b,p} G[b][p][n] * X[b][p + t][c],   db[n] = sum G[b][p][n]
+//
+// GEMM per tap: M = C_out (2 row tiles), N = C_in (1 tile), k = pixel pairs (98 per sample). Both operands have
+// the CHANNEL on the lane and the pixel along k - with channel-major images and odd channel strides every
+// fragment read is a conflict-free ds_read_b32 (the bf16 kernel needs transposing reads here). A block owns
+// (client, 1/NP of the taps, 1/NS of the batch) and walks its samples, so its accumulators are final sums: plain
+// stores (or per-split partials summed by conv2_wgrad_reduce_f32_kernel), no atomics, bitwise reproducible.
+// 8 waves = 4 tap groups x 2 row tiles; a wave shares its G value across its taps; the bias gradient rides along
+// as one more MFMA against ones. The next sample's rows are fetched into registers while this one is multiplied.
+// ---------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* g;    long g_cs;      // da2 [K][B][64][49]
+    const uint8_t* code; long c_cs;
+    const float* a1;   long a1_cs;     // [K][B][32][196]
+    float* dw;         long dw_cs;     // [K][64][32*T]
+    float* db;         long db_cs;     // [K][64]
+    int K, B;
+    float* part;       int NS;         // NS > 1: batch split, partials [K][NS][T*64*32 + 64]
+};
+
+template <int KS, int NP>
+__global__ __launch_bounds__(512) void conv2_wgrad_f32_kernel(WgradArgs a) {
+    using G = GeoF<KS>;
+    constexpr int T = G::T;
+    constexpr int NTAP = ((T + NP - 1) / NP + 3) / 4;    // most taps per wave
+    constexpr int GCS = CELLS1 + 1;                      // 197: odd channel stride of the routed gradient
+    constexpr int XN = CIN * G::CS, GN = COUT * GCS;
+    constexpr int NX4 = CIN * CELLS1 / 4;                // float4 of the activations of a sample: 1568
+    constexpr int XU = (NX4 + 511) / 512;                // per thread: 4
+    constexpr int NG = COUT * CELLS2;                    // pooled gradient values of a sample: 3136
+    constexpr int GU = (NG + 511) / 512;                 // per thread: 7
+    __shared__ __attribute__((aligned(16))) float ximg[(XN + 3) / 4 * 4];
+    __shared__ __attribute__((aligned(16))) float gimg[(GN + 3) / 4 * 4];
+
+    int c, sub;
+    if (!xcd_map(NP * a.NS, a.K, c, sub)) return;
+    const int tp = sub % NP, split = sub / NP;
+    const int b_begin = split * a.B / a.NS, b_end = (split + 1) * a.B / a.NS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int tg = wave >> 1, mt = wave & 1;
+    // taps of this block [p0, p0 + np) split over the four tap groups; (part 0, group 0) also owns the bias
+    const int p0 = tp * T / NP, np = (tp + 1) * T / NP - p0;
+    const int t_begin = p0 + tg * np / 4;
+    const int ntap = p0 + (tg + 1) * np / 4 - t_begin;
+    const bool do_bias = (tp == 0 && tg == 0);     // wave-uniform
+
+    for (int i = tid; i < (XN + 3) / 4; i += 512)
+        reinterpret_cast<f32x4*>(ximg)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < (GN + 3) / 4; i += 512)
+        reinterpret_cast<f32x4*>(gimg)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const float* xp[NTAP];
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j) {
+        const int t = min(t_begin + j, T - 1);
+        xp[j] = ximg + r * G::CS + h + (t / KS) * G::IW + (t % KS);
+    }
+    const float* gp = gimg + (mt * 32 + r) * GCS + h;
+
+    // staging roles (global -> registers -> LDS)
+    f32x4 xv[XU]; float gv[GU]; uint8_t qc[GU];
+    auto prefetch = [&](int b) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.a1 + c * a.a1_cs + (size_t)b * CIN * CELLS1);
+#pragma unroll
+        for (int u = 0; u < XU; ++u)
+            if (tid + 512 * u < NX4) xv[u] = src[tid + 512 * u];
+        const float* gs = a.g + c * a.g_cs + (size_t)b * NG;
+        const uint8_t* cs = a.code + c * a.c_cs + (size_t)b * NG;
+#pragma unroll
+        for (int u = 0; u < GU; ++u)
+            if (tid + 512 * u < NG) { gv[u] = gs[tid + 512 * u]; qc[u] = cs[tid + 512 * u]; }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = tid + 512 * u;
+            if (i < NX4) {
+                const int ch = i / (CELLS1 / 4), j = i - ch * (CELLS1 / 4);
+                float* dst = ximg + ch * G::CS + G::PAD * G::IW + G::PAD;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int p = 4 * j + e, y = p / P1, x = p - y * P1;
+                    dst[y * G::IW + x] = xv[u][e];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int i = tid + 512 * u;
+            if (i < NG) {
+                const int co = i / CELLS2, cell = i - co * CELLS2;
+                float* dst = gimg + co * GCS + 2 * (cell / P2) * P1 + 2 * (cell % P2);
+                const int q = qc[u];
+                dst[0] = q == 0 ? gv[u] : 0.f;
+                dst[1] = q == 1 ? gv[u] : 0.f;
+                dst[P1] = q == 2 ? gv[u] : 0.f;
+                dst[P1 + 1] = q == 3 ? gv[u] : 0.f;
+            }
+        }
+    };
+
+    f32x16 acc[NTAP], accb;
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accb[e] = 0.f;
+
+    if (b_begin < b_end) prefetch(b_begin);
+    for (int item = b_begin; item < b_end; ++item) {
+        __syncthreads();            // everyone finished reading the previous images (or zero-filling)
+        commit();
+        __syncthreads();
+        if (item + 1 < b_end) prefetch(item + 1);
+
+#pragma unroll 2
+        for (int y = 0; y < P1; ++y) {
+#pragma unroll
+            for (int xs = 0; xs < P1 / 2; ++xs) {
+                const float av = gp[y * P1 + 2 * xs];
+#pragma unroll
+                for (int j = 0; j < NTAP; ++j)
+                    if (j < ntap)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xp[j][y * G::IW + 2 * xs], acc[j], 0, 0, 0);
+                if (do_bias) accb = __builtin_amdgcn_mfma_f32_32x32x2f32(av, 1.0f, accb, 0, 0, 0);
+            }
+        }
+    }
+
+    const int ci = r;
+    if (a.NS > 1) {
+        // partial of this batch split, tap-major [t][n][ci], then the bias
+        float* pw = a.part + ((size_t)c * a.NS + split) * (T * COUT * CIN + COUT);
+#pragma unroll
+        for (int j = 0; j < NTAP; ++j) {
+            if (j < ntap) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    pw[((t_begin + j) * COUT + mt * 32 + mfma_row_(e, lane)) * CIN + ci] = acc[j][e];
+            }
+        }
+        if (do_bias && ci == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) pw[T * COUT * CIN + mt * 32 + mfma_row_(e, lane)] = accb[e];
+        }
+        return;
+    }
+    float* dw = a.dw + c * a.dw_cs;
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j) {
+        if (j < ntap) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = mt * 32 + mfma_row_(e, lane);
+                dw[((size_t)n * CIN + ci) * T + t_begin + j] = acc[j][e];
+            }
+        }
+    }
+    if (do_bias && ci == 0) {
+        float* db = a.db + c * a.db_cs;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) db[mt * 32 + mfma_row_(e, lane)] = accb[e];
+    }
+}
+
+// Sum of the NS batch-split partials [t][n][ci] -> dW[n][ci][t], db[n]. One block per (client, n).
+template <int KS>
+__global__ __launch_bounds__(256) void conv2_wgrad_reduce_f32_kernel(WgradArgs a) {
+    constexpr int T = KS * KS, NW = T * COUT * CIN, PW = NW + COUT;
+    __shared__ float tr[CIN * T];
+    const int c = blockIdx.y, n = blockIdx.x;
+    const float* p = a.part + (size_t)c * a.NS * PW;
+    for (int i = threadIdx.x; i < CIN * T; i += 256) {
+        const int t = i / CIN, ci = i % CIN;
+        float s = 0.f;
+        for (int k = 0; k < a.NS; ++k) s += p[(size_t)k * PW + (t * COUT + n) * CIN + ci];
+        tr[ci * T + t] = s;
+    }
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int k = 0; k < a.NS; ++k) s += p[(size_t)k * PW + NW + n];
+        a.db[c * a.db_cs + n] = s;
+    }
+    __syncthreads();
+    float* dw = a.dw + c * a.dw_cs + (size_t)n * CIN * T;
+    for (int i = threadIdx.x; i < CIN * T; i += 256) dw[i] = tr[i];
+}
+
+int num_cus() {
+    static int n = 0;
+    if (n <= 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+    }
+    return n;
+}
+
+// Work split of the fp32 weight gradient: np tap parts x ns batch splits per client. The kernel is matrix-pipe-
+// bound and runs one 8-wave block per CU, so what counts is how evenly the MFMAs are dealt: whole waves of
+// blocks over the CUs, samples over the batch splits, taps over the four tap groups of a block. Tap parts
+// multiply the staging work and batch splits the partial-sum traffic (small penalties).
+//   5x5: 100 clients -> 1 x 5 (500 blocks = 1.95 waves), 10 -> 5 x 5;  3x3: 1000 -> 1 x 1, 50 -> 1 x 5
+void wgrad_split_f32(int K, int B, int KS, int cus, int& np, int& ns) {
+    static const int parts[3] = {1, 2, 5};
+    const int T = KS * KS;
+    double best = -1.0;
+    np = 1; ns = 1;
+    for (int i = 0; i < 3; ++i) {
+        const int p = parts[i];
+        if (p > T) continue;
+        const int ntap = ((T + p - 1) / p + 3) / 4;
+        const double tapbal = (double)T / (p * 4 * ntap);
+        for (int s = 1; s <= 8 && s <= B; ++s) {
+            const long blocks = (long)K * p * s;
+            const double fill = (double)blocks / ((double)((blocks + cus - 1) / cus) * cus);
+            const double bbal = (double)B / (s * ((B + s - 1) / s));
+            const double e = tapbal * fill * bbal / (1.0 + 0.05 * (p - 1)) / (1.0 + 0.01 * (s - 1));
+            if (e > best) { best = e; np = p; ns = s; }
+        }
+    }
+}
+
+template <int KS>
+void launch_wgrad(const WgradArgs& a, int np, hipStream_t stream) {
+    const dim3 block(512);
+    const int slots = cdiv(a.K, 8) * 8 * a.NS;
+    if (np == 1) hipLaunchKernelGGL((conv2_wgrad_f32_kernel<KS, 1>), dim3(slots), block, 0, stream, a);
+    else if (np == 2) hipLaunchKernelGGL((conv2_wgrad_f32_kernel<KS, 2>), dim3(slots * 2), block, 0, stream, a);
+    else hipLaunchKernelGGL((conv2_wgrad_f32_kernel<KS, 5>), dim3(slots * 5), block, 0, stream, a);
+    if (a.NS > 1)
+        hipLaunchKernelGGL(conv2_wgrad_reduce_f32_kernel<KS>, dim3(COUT, a.K), dim3(256), 0, stream, a);
+}
+
+}  // namespace
+
+int conv2_prep_f32(const float* w, long w_cs, float* wp, long wp_cs, int K, int KS, hipStream_t stream) {
+    if (K <= 0) return -1;
+    if (wp_cs < 2L * KS * KS * COUT * CIN || (wp_cs & 3) || ((uintptr_t)wp & 15)) return -2;
+    dim3 grid(cdiv(COUT * CIN * KS * KS, 256 * 4), K);
+    if (KS == 5) hipLaunchKernelGGL(conv2_prep_f32_kernel<5>, grid, dim3(256), 0, stream, w, w_cs, wp, wp_cs);
+    else if (KS == 3) hipLaunchKernelGGL(conv2_prep_f32_kernel<3>, grid, dim3(256), 0, stream, w, w_cs, wp, wp_cs);
+    else return -3;
+    P2PFL_RETURN_LAST_ERROR();
+}
+
+int conv2_fwd_f32(const float* a1, long a1_cs, const float* wp, long wp_cs, const float* bias, long b_cs, float* a2,
+                  long a2_cs, uint8_t* code, long c_cs, int K, int B, int KS, hipStream_t stream) {
+    if (K <= 0 || B <= 0) return -1;
+    if ((wp_cs & 3) || ((uintptr_t)wp & 15) || ((uintptr_t)a1 & 15) || (a1_cs & 3)) return -2;
+    if (((uintptr_t)a2 & 15) || (a2_cs & 3) || ((uintptr_t)code & 15) || (c_cs & 15)) return -2;   // 16-byte block stores
+    FwdArgs a{a1, a1_cs, wp, wp_cs, bias, b_cs, a2, a2_cs, code, c_cs, K, B};
+    dim3 grid(cdiv(K, 8) * 8 * cdiv(B, 2));
+    if (KS == 5) hipLaunchKernelGGL(conv2_fwd_f32_kernel<5>, grid, dim3(256), 0, stream, a);
+    else if (KS == 3) hipLaunchKernelGGL(conv2_fwd_f32_kernel<3>, grid, dim3(256), 0, stream, a);
+    else return -3;
+    P2PFL_RETURN_LAST_ERROR();
+}
+
+int conv2_dgrad_f32(const float* g, long g_cs, const uint8_t* code, long c_cs, const float* wp, long wp_cs,
+                    float* da1, long da1_cs, int K, int B, int KS, hipStream_t stream) {
+    if (K <= 0 || B <= 0) return -1;
+    if ((wp_cs & 3) || ((uintptr_t)wp & 15) || (da1_cs & 3) || ((uintptr_t)da1 & 15)) return -2;
+    DgradArgs a{g, g_cs, code, c_cs, wp, wp_cs, da1, da1_cs, K, B};
+    dim3 grid(cdiv(K, 8) * 8 * B);
+    if (KS == 5) hipLaunchKernelGGL(conv2_dgrad_f32_kernel<5>, grid, dim3(256), 0, stream, a);
+    else if (KS == 3) hipLaunchKernelGGL(conv2_dgrad_f32_kernel<3>, grid, dim3(256), 0, stream, a);
+    else return -3;
+    P2PFL_RETURN_LAST_ERROR();
+}
+
+long conv2_wgrad_f32_scratch(int K, int B, int KS) {
+    if (K <= 0 || B <= 0) return 0;
+    int np, ns;
+    wgrad_split_f32(K, B, KS, num_cus(), np, ns);
+    return ns > 1 ? (long)K * ns * (KS * KS * COUT * CIN + COUT) : 0;
+}
+
+int conv2_wgrad_f32(const float* g, long g_cs, const uint8_t* code, long c_cs, const float* a1, long a1_cs, float* dw,
+                    long dw_cs, float* db, long db_cs, float* scratch, long scratch_floats, int K, int B, int KS,
+                    hipStream_t stream) {
+    if (K <= 0 || B <= 0) return -1;
+    if (((uintptr_t)a1 & 15) || (a1_cs & 3)) return -2;
+    int np, ns;
+    wgrad_split_f32(K, B, KS, num_cus(), np, ns);
+    if (scratch == nullptr || scratch_floats < (long)K * ns * (KS * KS * COUT * CIN + COUT)) ns = 1;
+    WgradArgs a{g, g_cs, code, c_cs, a1, a1_cs, dw, dw_cs, db, db_cs, K, B, scratch, ns};
+    if (KS == 5) launch_wgrad<5>(a, np, stream);
+    else if (KS == 3) launch_wgrad<3>(a, np, stream);
+    else return -3;
+    P2PFL_RETURN_LAST_ERROR();
+}

@@ -3,17 +3,23 @@
 //   C[m][n] = sum_k A[m][k] * B[n][k]          (both operands presented "k-contiguous")
 //
 // Operands are produced by *loader functors* (arbitrary addressing: plain row-major,
-// transposed, im2col gathers, pool-routed gradients ...) as fp32, rounded to bf16 on
-// the way into LDS, multiplied on the matrix cores with
-// v_mfma_f32_32x32x16_bf16 (fp32 accumulate) and handed tile-by-tile to an
-// *epilogue functor* (bias/ReLU/pool/optimizer fusions live there).
+// transposed, im2col gathers, pool-routed gradients ...) as fp32 and handed tile-by-tile to an
+// *epilogue functor* (bias/ReLU/pool/optimizer fusions live there). The element type T of the LDS
+// tiles is the precision policy of the product:
+//   T = float  : operands stay fp32, v_mfma_f32_32x32x2_f32 - bit-for-bit an fp32 fma chain (the
+//                precision of the reference, whose Trainer runs 32-bit:
+//                fedstellar/learning/pytorch/lightninglearner.py:182-193). Default.
+//   T = __bf16 : operands rounded to bf16 on the way into LDS, v_mfma_f32_32x32x16_bf16 with fp32
+//                accumulation (16x the matrix rate; the labelled fast mode).
 //
 // Geometry (64-lane waves):  block = WR x WC waves, block tile BM x BN, BK = 32 (default; 64 / 128 for
 // weight-streaming products with a long reduction, where a 32-deep step is latency- not bandwidth-bound).
 // Each wave owns (BM/WR) x (BN/WC) outputs = RM x RN tiles of 32x32.
-// LDS rows hold BK bf16 + 8 pad (80 / 144 / 272 B = an odd multiple of 16 B): every 16-lane
-// ds_read_b128 group lands on 16 distinct 16-B slots of the 256-B bank row, so fragment reads are
-// conflict-free.
+// LDS rows hold BK elements + 16 B pad (bf16: 80 / 144 / 272 B, fp32: 144 / 272 / 528 B = an odd multiple
+// of 16 B): every 16-lane ds_read_b128 group lands on 16 distinct 16-B slots of the 256-B bank row, so
+// fragment reads are conflict-free. An fp32 fragment read hands lane (r, h) the four values k = 4h .. 4h+3 of
+// an 8-deep chunk; MFMA e of the chunk multiplies element e of both operands, i.e. reduces the k pair
+// (e, 4 + e) - the order inside the reduction is free as long as both operands agree on it.
 // Staging is register-split (issue global loads for tile t+1, run the MFMAs of tile t,
 // then write t+1 into the other LDS buffer): one barrier per K-step.
 //
@@ -29,7 +35,19 @@
 #include "common.h"
 
 constexpr int GEMM_BK = 32;
-constexpr int GEMM_LDK = 40;  // bf16 elements per LDS row (32 data + 8 pad)
+
+template <class T> struct is_f32 { static constexpr bool value = false; };
+template <> struct is_f32<float> { static constexpr bool value = true; };
+// elements of padding per LDS row (16 B)
+template <class T> constexpr int lds_pad() { return 16 / (int)sizeof(T); }
+
+__device__ __forceinline__ void store_chunk(__bf16* dst, const float (&v)[8]) {
+    *reinterpret_cast<bf16x8*>(dst) = pack_bf16x8(v);
+}
+__device__ __forceinline__ void store_chunk(float* dst, const float (&v)[8]) {
+    *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
 
 __device__ __forceinline__ int mfma_row(int reg, int lane) {
     return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
@@ -38,11 +56,11 @@ __device__ __forceinline__ int mfma_row(int reg, int lane) {
 // PERM4 (ROWS % 128 == 0; per 128-row block): LDS row rho holds global row 4*(rho & 31) + (rho >> 5). With four
 // 32-column MFMA tiles per wave this puts output columns 4r..4r+3 into the four accumulators of
 // lane r, so an epilogue can move float4 (16 B) per lane along the contiguous output dimension.
-template <int ROWS, int NT, class Loader, bool PERM4 = false, int BK = GEMM_BK>
+template <int ROWS, int NT, class Loader, bool PERM4 = false, int BK = GEMM_BK, class T = __bf16>
 struct TileStager {
     static constexpr int KC = BK / 8;                          // chunks per row
-    static constexpr int LDK = BK + 8;
-    static constexpr int CHUNKS = ROWS * KC;                   // 16-B (8 x bf16) chunks per tile
+    static constexpr int LDK = BK + lds_pad<T>();
+    static constexpr int CHUNKS = ROWS * KC;                   // 8-element chunks per tile
     static constexpr int PER_THREAD = (CHUNKS + NT - 1) / NT;  // chunks each thread moves
     float v[PER_THREAD][8];
 
@@ -61,13 +79,13 @@ struct TileStager {
             }
         }
     }
-    __device__ __forceinline__ void store(__bf16* lds) const {
+    __device__ __forceinline__ void store(T* lds) const {
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
             int c = threadIdx.x + i * NT;
             if (CHUNKS % NT == 0 || c < CHUNKS) {
                 int row, k8; decode(c, row, k8);
-                *reinterpret_cast<bf16x8*>(lds + row * LDK + k8 * 8) = pack_bf16x8(v[i]);
+                store_chunk(lds + row * LDK + k8 * 8, v[i]);
             }
         }
     }
@@ -76,10 +94,10 @@ struct TileStager {
 // NBUF = 2: double-buffered staging (one barrier per k-step). NBUF = 1: a single buffer (two barriers
 // per k-step) for products whose reduction is one or two k-steps deep, where the second buffer would
 // only cost occupancy (weight gradients: k = batch = 32).
-template <int BM, int BN, int NBUF = 2, int BK = GEMM_BK>
+template <int BM, int BN, int NBUF = 2, int BK = GEMM_BK, class T = __bf16>
 struct GemmSmem {
-    __bf16 a[NBUF][BM * (BK + 8)];
-    __bf16 b[NBUF][BN * (BK + 8)];
+    T a[NBUF][BM * (BK + lds_pad<T>())];
+    T b[NBUF][BN * (BK + lds_pad<T>())];
 };
 
 // Runs one BM x BN block tile over k in [k_begin, k_end) (k_begin % 32 == 0; loaders
@@ -87,12 +105,13 @@ struct GemmSmem {
 // N4 = true (needs 128-column wave tiles, BN = 128 * WC): B is staged with the PERM4 row permutation and the epilogue
 // is called as  epi.store4(float4 v, int m, int n)  with v = C[m][n .. n+3], n % 4 == 0.
 template <int BM, int BN, int WR, int WC, class AL, class BL, class EPI, bool N4 = false, int NBUF = 2,
-          int BK = GEMM_BK>
-__device__ __forceinline__ void gemm_block_tile(GemmSmem<BM, BN, NBUF, BK>& sm, const AL& al, const BL& bl,
+          int BK = GEMM_BK, class T = __bf16>
+__device__ __forceinline__ void gemm_block_tile(GemmSmem<BM, BN, NBUF, BK, T>& sm, const AL& al, const BL& bl,
                                                 const EPI& epi, int m0, int n0, int k_begin,
                                                 int k_end) {
     constexpr int NT = 64 * WR * WC;
-    constexpr int LDK = BK + 8;
+    constexpr int LDK = BK + lds_pad<T>();
+    constexpr int HK = is_f32<T>::value ? 4 : 8;     // elements per lane half of a fragment read
     constexpr int TM = BM / WR, TN = BN / WC;
     constexpr int RM = TM / 32, RN = TN / 32;
     static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of 32x32");
@@ -110,8 +129,8 @@ __device__ __forceinline__ void gemm_block_tile(GemmSmem<BM, BN, NBUF, BK>& sm, 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    TileStager<BM, NT, AL, false, BK> sa;
-    TileStager<BN, NT, BL, N4, BK> sb;
+    TileStager<BM, NT, AL, false, BK, T> sa;
+    TileStager<BN, NT, BL, N4, BK, T> sb;
     static_assert(!N4 || TN == 128, "N4 epilogue needs 128-column wave tiles");
 
     sa.load(al, m0, k_begin);
@@ -127,22 +146,42 @@ __device__ __forceinline__ void gemm_block_tile(GemmSmem<BM, BN, NBUF, BK>& sm, 
             sa.load(al, m0, k + BK);
             sb.load(bl, n0, k + BK);
         }
-        const __bf16* as = sm.a[cur] + (wr * TM + r) * LDK + h * 8;
-        const __bf16* bs = sm.b[cur] + (wc * TN + r) * LDK + h * 8;
+        const T* as = sm.a[cur] + (wr * TM + r) * LDK + h * HK;
+        const T* bs = sm.b[cur] + (wc * TN + r) * LDK + h * HK;
+        if constexpr (is_f32<T>::value) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8 af[RM], bfr[RN];
+            for (int kk = 0; kk < BK / 8; ++kk) {
+                f32x4 af[RM], bfr[RN];
 #pragma unroll
-            for (int i = 0; i < RM; ++i)
-                af[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * LDK + kk * 16);
-#pragma unroll
-            for (int j = 0; j < RN; ++j)
-                bfr[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * LDK + kk * 16);
-#pragma unroll
-            for (int i = 0; i < RM; ++i)
+                for (int i = 0; i < RM; ++i)
+                    af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDK + kk * 8);
 #pragma unroll
                 for (int j = 0; j < RN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    bfr[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDK + kk * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < RM; ++i)
+#pragma unroll
+                        for (int j = 0; j < RN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bfr[j][e], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                bf16x8 af[RM], bfr[RN];
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+                    af[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * LDK + kk * 16);
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+                    bfr[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * LDK + kk * 16);
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+#pragma unroll
+                    for (int j = 0; j < RN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
         }
         if constexpr (NBUF == 2) {
             if (has_next) {

@@ -39,16 +39,16 @@ struct EpiBiasAct {
 };
 
 // y = act(x W^T + b);  M = B, N = Out, K = In
-template <int BK, int NBUF>
+template <int BK, int NBUF, class T>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(LinearArgs a) {
-    __shared__ GemmSmem<32, 128, NBUF, BK> sm;
+    __shared__ GemmSmem<32, 128, NBUF, BK, T> sm;
     const int c = blockIdx.z;
     const float* x = a.x + c * a.x_cs;
     const float* w = a.w + c * a.w_cs;
     LoadRowMajorK al{x, a.B, a.In, a.In, (bool)(a.vec & 1), a.sidx ? a.sidx + c * a.s_cs : nullptr};
     LoadRowMajorK bl{w, a.Out, a.In, a.In, (bool)(a.vec & 2)};
     EpiBiasAct epi{a.y + c * a.y_cs, a.b + c * a.b_cs, a.B, a.Out, a.relu};
-    gemm_block_tile<32, 128, 1, 4, LoadRowMajorK, LoadRowMajorK, EpiBiasAct, false, NBUF, BK>(
+    gemm_block_tile<32, 128, 1, 4, LoadRowMajorK, LoadRowMajorK, EpiBiasAct, false, NBUF, BK, T>(
         sm, al, bl, epi, blockIdx.y * 32, blockIdx.x * 128, 0, a.In);
 }
 
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(LinearArgs a) {
 // tile, so the LDS pipeline above runs 10..100 blocks that each wait a full HBM latency per k-step (49 us for
 // 2048 -> 10). Here the 16 waves of a block split the reduction, fetch their MFMA fragments straight from
 // global memory with several k-steps in flight, and add their partial tiles up through LDS.
-template <int NT, int U>
+template <int NT, int U, bool F32>
 __global__ __launch_bounds__(1024) void linear_fwd_skinny_kernel(LinearArgs a) {
     __shared__ float red[16][16][64];
     const int c = blockIdx.z, m0 = blockIdx.y * 32;
@@ -88,10 +88,18 @@ __global__ __launch_bounds__(1024) void linear_fwd_skinny_kernel(LinearArgs a) {
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bf16x8 af = pack_bf16x8(xv[u]);
+            if constexpr (F32) {      // lane half h holds k = 8h .. 8h+7: MFMA e reduces the pair (e, 8 + e)
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pack_bf16x8(wv[u][j]), acc[j], 0, 0, 0);
+                for (int e = 0; e < 8; ++e)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[u][e], wv[u][j][e], acc[j], 0, 0, 0);
+            } else {
+                const bf16x8 af = pack_bf16x8(xv[u]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pack_bf16x8(wv[u][j]), acc[j], 0, 0, 0);
+            }
         }
     }
     float* y = a.y + c * a.y_cs;
@@ -168,14 +176,14 @@ struct EpiMaskStore {
 };
 
 // dx = (dy W) * [act > 0];  M = B, N = In, K = Out
-template <int BK, int NBUF>
+template <int BK, int NBUF, class T>
 __global__ __launch_bounds__(256) void linear_dgrad_kernel(DgradArgs a) {
-    __shared__ GemmSmem<32, 128, NBUF, BK> sm;
+    __shared__ GemmSmem<32, 128, NBUF, BK, T> sm;
     const int c = blockIdx.z;
     LoadRowMajorK al{a.dy + c * a.dy_cs, a.B, a.Out, a.Out, (bool)a.vec};
     LoadColMajorK bl{a.w + c * a.w_cs, a.In, a.Out, a.In};
     EpiMaskStore epi{a.dx + c * a.dx_cs, a.act ? a.act + c * a.act_cs : nullptr, a.B, a.In};
-    gemm_block_tile<32, 128, 1, 4, LoadRowMajorK, LoadColMajorK, EpiMaskStore, false, NBUF, BK>(
+    gemm_block_tile<32, 128, 1, 4, LoadRowMajorK, LoadColMajorK, EpiMaskStore, false, NBUF, BK, T>(
         sm, al, bl, epi, blockIdx.y * 32, blockIdx.x * 128, 0, a.Out);
 }
 
@@ -238,13 +246,14 @@ struct EpiWgradStore {
 };
 
 // dW = dy^T x, db = dy^T 1;  M = Out, N = In + 1, K = B
+template <class T>
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(WgradArgs a) {
-    __shared__ GemmSmem<128, 128> sm;
+    __shared__ GemmSmem<128, 128, 1, GEMM_BK, T> sm;
     const int c = blockIdx.z;
     LoadColMajorK al{a.dy + c * a.dy_cs, a.Out, a.B, a.Out};
     LoadXTOnes bl{a.x + c * a.x_cs, a.In, a.B, a.sidx ? a.sidx + c * a.s_cs : nullptr};
     EpiWgradStore epi{a.dw + c * a.dw_cs, a.db + c * a.db_cs, a.Out, a.In};
-    gemm_block_tile<128, 128, 4, 1, LoadColMajorK, LoadXTOnes, EpiWgradStore, true>(
+    gemm_block_tile<128, 128, 4, 1, LoadColMajorK, LoadXTOnes, EpiWgradStore, true, 1, GEMM_BK, T>(
         sm, al, bl, epi, blockIdx.y * 128, blockIdx.x * 128, 0, a.B);
 }
 
@@ -349,12 +358,12 @@ constexpr int PIN_UPDATE_MAX_CLIENTS = 80;    // measured: pinned wins by 5-8 % 
 constexpr int UPDATE_KERNEL_RESERVE = 12;      // -> 188 VGPRs: two waves per SIMD, 2 x 64 left for a convolution block
                                                // (pinned by tests/test_host_sanitizers.py::test_fused_update_occupancy)
 
-template <int WR, int WC, bool FRESH, int RESERVE>
+template <int WR, int WC, bool FRESH, int RESERVE, class T>
 __global__ __launch_bounds__(256, 2)
 void linear_wgrad_adam_kernel(WgradAdamArgs a) {
     RegisterReserve<RESERVE> reserve;
     constexpr int BM = 32 * WR, BN = 128 * WC;
-    __shared__ GemmSmem<BM, BN, 1> sm;
+    __shared__ GemmSmem<BM, BN, 1, GEMM_BK, T> sm;
     const int c = blockIdx.z;
     LoadColMajorK al{a.dy + c * a.dy_cs, a.Out, a.B, a.Out};
     LoadXTOnes bl{a.x + c * a.x_cs, a.In, a.B, a.sidx ? a.sidx + c * a.s_cs : nullptr};
@@ -363,7 +372,7 @@ void linear_wgrad_adam_kernel(WgradAdamArgs a) {
     const long wo = c * a.w_cs, bo = c * a.b_cs;
     EpiWgradAdam<FRESH> epi{a.w + wo, a.mw + wo, a.vw + wo, a.b + bo, a.mb + bo, a.vb + bo, a.Out, a.In,
                             a.h.lr * ib1, a.h.beta1, a.h.beta2, a.h.eps, a.h.weight_decay, isb2};
-    gemm_block_tile<BM, BN, WR, WC, LoadColMajorK, LoadXTOnes, EpiWgradAdam<FRESH>, true, 1>(
+    gemm_block_tile<BM, BN, WR, WC, LoadColMajorK, LoadXTOnes, EpiWgradAdam<FRESH>, true, 1, GEMM_BK, T>(
         sm, al, bl, epi, blockIdx.y * BM, blockIdx.x * BN, 0, a.B);
     reserve.release();
 }
@@ -420,16 +429,16 @@ struct WgradSgdmArgs {
     const int* sidx; long s_cs;
 };
 
-template <bool FRESH>
+template <bool FRESH, class T>
 __global__ __launch_bounds__(256, 2)
 void linear_wgrad_sgdm_kernel(WgradSgdmArgs a) {
-    __shared__ GemmSmem<128, 128, 1> sm;
+    __shared__ GemmSmem<128, 128, 1, GEMM_BK, T> sm;
     const int c = blockIdx.z;
     LoadColMajorK al{a.dy + c * a.dy_cs, a.Out, a.B, a.Out};
     LoadXTOnes bl{a.x + c * a.x_cs, a.In, a.B, a.sidx ? a.sidx + c * a.s_cs : nullptr};
     const long wo = c * a.w_cs, bo = c * a.b_cs;
     EpiWgradSgdm<FRESH> epi{a.w + wo, a.mw + wo, a.b + bo, a.mb + bo, a.Out, a.In, a.lr, a.momentum, a.weight_decay};
-    gemm_block_tile<128, 128, 4, 1, LoadColMajorK, LoadXTOnes, EpiWgradSgdm<FRESH>, true, 1>(
+    gemm_block_tile<128, 128, 4, 1, LoadColMajorK, LoadXTOnes, EpiWgradSgdm<FRESH>, true, 1, GEMM_BK, T>(
         sm, al, bl, epi, blockIdx.y * 128, blockIdx.x * 128, 0, a.B);
 }
 
@@ -452,7 +461,7 @@ P2PFL_API int p2pfl_linear_wgrad_adam(const float* dy, long dy_cs, const float* 
                                       float* mw, float* vw, long w_cs, float* b, float* mb, float* vb,
                                       long b_cs, int K, int B, int In, int Out, float lr, float beta1,
                                       float beta2, float eps, float weight_decay, int t, const float* bc,
-                                      int fresh, const int* sidx, long s_cs, hipStream_t stream) {
+                                      int fresh, const int* sidx, long s_cs, int prec, hipStream_t stream) {
     if (K <= 0 || B <= 0 || In <= 0 || Out <= 0 || t <= 0) return -1;
     const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
     WgradAdamArgs a{dy, dy_cs, x, x_cs, w, mw, vw, w_cs, b, mb, vb, b_cs, B, In, Out,
@@ -465,13 +474,16 @@ P2PFL_API int p2pfl_linear_wgrad_adam(const float* dy, long dy_cs, const float* 
     // many clients: the side branch has slack and three resident workgroups stream a little faster
     const char* pin_env = getenv("P2PFL_PIN_UPDATE");
     const bool pin = pin_env ? atoi(pin_env) != 0 : K <= PIN_UPDATE_MAX_CLIENTS;
-    if (pin) {
+    if (prec == PREC_F32) {
+        if (fresh) hipLaunchKernelGGL((linear_wgrad_adam_kernel<4, 1, true, 0, float>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((linear_wgrad_adam_kernel<4, 1, false, 0, float>), grid, dim3(256), 0, stream, a);
+    } else if (pin) {
         constexpr int R = UPDATE_KERNEL_RESERVE;
-        if (fresh) hipLaunchKernelGGL((linear_wgrad_adam_kernel<4, 1, true, R>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((linear_wgrad_adam_kernel<4, 1, false, R>), grid, dim3(256), 0, stream, a);
+        if (fresh) hipLaunchKernelGGL((linear_wgrad_adam_kernel<4, 1, true, R, __bf16>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((linear_wgrad_adam_kernel<4, 1, false, R, __bf16>), grid, dim3(256), 0, stream, a);
     } else {
-        if (fresh) hipLaunchKernelGGL((linear_wgrad_adam_kernel<4, 1, true, 0>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((linear_wgrad_adam_kernel<4, 1, false, 0>), grid, dim3(256), 0, stream, a);
+        if (fresh) hipLaunchKernelGGL((linear_wgrad_adam_kernel<4, 1, true, 0, __bf16>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((linear_wgrad_adam_kernel<4, 1, false, 0, __bf16>), grid, dim3(256), 0, stream, a);
     }
     P2PFL_RETURN_LAST_ERROR();
 }
@@ -479,13 +491,18 @@ P2PFL_API int p2pfl_linear_wgrad_adam(const float* dy, long dy_cs, const float* 
 P2PFL_API int p2pfl_linear_wgrad_sgdm(const float* dy, long dy_cs, const float* x, long x_cs, float* w,
                                       float* mw, long w_cs, float* b, float* mb, long b_cs, int K, int B,
                                       int In, int Out, float lr, float momentum, float weight_decay,
-                                      int fresh, const int* sidx, long s_cs, hipStream_t stream) {
+                                      int fresh, const int* sidx, long s_cs, int prec, hipStream_t stream) {
     if (K <= 0 || B <= 0 || In <= 0 || Out <= 0) return -1;
     WgradSgdmArgs a{dy, dy_cs, x, x_cs, w, mw, w_cs, b, mb, b_cs, B, In, Out, lr, momentum, weight_decay, fresh,
                     sidx, s_cs};
     const dim3 grid(cdiv(In + 1, 128), cdiv(Out, 128), K);
-    if (fresh) hipLaunchKernelGGL(linear_wgrad_sgdm_kernel<true>, grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(linear_wgrad_sgdm_kernel<false>, grid, dim3(256), 0, stream, a);
+    if (prec == PREC_F32) {
+        if (fresh) hipLaunchKernelGGL((linear_wgrad_sgdm_kernel<true, float>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((linear_wgrad_sgdm_kernel<false, float>), grid, dim3(256), 0, stream, a);
+    } else {
+        if (fresh) hipLaunchKernelGGL((linear_wgrad_sgdm_kernel<true, __bf16>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((linear_wgrad_sgdm_kernel<false, __bf16>), grid, dim3(256), 0, stream, a);
+    }
     P2PFL_RETURN_LAST_ERROR();
 }
 
@@ -508,7 +525,7 @@ P2PFL_API long p2pfl_linear_fwd_scratch(int K, int B, int In, int Out) {
 P2PFL_API int p2pfl_linear_fwd(const float* x, long x_cs, const float* w, long w_cs, const float* b,
                                long b_cs, float* y, long y_cs, int K, int B, int In, int Out,
                                int relu, const int* sidx, long s_cs, float* scratch, long scratch_floats,
-                               hipStream_t stream) {
+                               int prec, hipStream_t stream) {
     if (K <= 0 || B <= 0 || In <= 0 || Out <= 0) return -1;
     // float4 loads need In % 4 == 0 and 16-B aligned bases/strides; otherwise element loads
     const int xv = !((In & 3) || (x_cs & 3) || ((uintptr_t)x & 15));
@@ -520,8 +537,11 @@ P2PFL_API int p2pfl_linear_fwd(const float* x, long x_cs, const float* w, long w
         const int nt = Out <= 32 ? 1 : 2;
         if (scratch == nullptr || scratch_floats < (long)K * cdiv(B, 32) * ks * nt * 1024) ks = 1;
         const dim3 sgrid(ks, cdiv(B, 32), K), rgrid(1, cdiv(B, 32), K);
-        if (nt == 1) hipLaunchKernelGGL((linear_fwd_skinny_kernel<1, 4>), sgrid, dim3(1024), 0, stream, a);
-        else hipLaunchKernelGGL((linear_fwd_skinny_kernel<2, 2>), sgrid, dim3(1024), 0, stream, a);
+        const bool f32 = prec == PREC_F32;
+        if (nt == 1 && f32) hipLaunchKernelGGL((linear_fwd_skinny_kernel<1, 4, true>), sgrid, dim3(1024), 0, stream, a);
+        else if (nt == 1) hipLaunchKernelGGL((linear_fwd_skinny_kernel<1, 4, false>), sgrid, dim3(1024), 0, stream, a);
+        else if (f32) hipLaunchKernelGGL((linear_fwd_skinny_kernel<2, 2, true>), sgrid, dim3(1024), 0, stream, a);
+        else hipLaunchKernelGGL((linear_fwd_skinny_kernel<2, 2, false>), sgrid, dim3(1024), 0, stream, a);
         if (ks > 1) {
             if (nt == 1) hipLaunchKernelGGL(linear_skinny_reduce_kernel<1>, rgrid, dim3(1024), 0, stream, a, ks);
             else hipLaunchKernelGGL(linear_skinny_reduce_kernel<2>, rgrid, dim3(1024), 0, stream, a, ks);
@@ -535,33 +555,44 @@ P2PFL_API int p2pfl_linear_fwd(const float* x, long x_cs, const float* w, long w
     const bool sparse_grid = (long)grid.x * grid.y * grid.z <= num_cus() && getenv("P2PFL_NO_BK128") == nullptr;
     // (single-buffered 64- / 128-deep variants: 528 us against 516-528 double-buffered 64-deep; 128-deep x 2: 640;
     //  32 x 64 tiles with 2 waves, i.e. twice the blocks: 549 us with 64-deep, 609 us with 128-deep steps)
-    if (In >= 1024 && sparse_grid) hipLaunchKernelGGL((linear_fwd_kernel<128, 2>), grid, dim3(256), 0, stream, a);
-    else if (In >= 1024) hipLaunchKernelGGL((linear_fwd_kernel<64, 2>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((linear_fwd_kernel<32, 2>), grid, dim3(256), 0, stream, a);
+    if (prec == PREC_F32) {
+        // fp32 tiles are twice the bytes: 32-deep steps x 2 buffers = the LDS footprint (46 KB, 3 workgroups per
+        // CU) of the 64-deep bf16 variant; 64-deep (87 KB, one workgroup per CU) only for grids below one block per CU
+        if (In >= 1024 && sparse_grid) hipLaunchKernelGGL((linear_fwd_kernel<64, 2, float>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((linear_fwd_kernel<32, 2, float>), grid, dim3(256), 0, stream, a);
+    }
+    else if (In >= 1024 && sparse_grid) hipLaunchKernelGGL((linear_fwd_kernel<128, 2, __bf16>), grid, dim3(256), 0, stream, a);
+    else if (In >= 1024) hipLaunchKernelGGL((linear_fwd_kernel<64, 2, __bf16>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((linear_fwd_kernel<32, 2, __bf16>), grid, dim3(256), 0, stream, a);
     P2PFL_RETURN_LAST_ERROR();
 }
 
 P2PFL_API int p2pfl_linear_dgrad(const float* dy, long dy_cs, const float* w, long w_cs,
                                  const float* act, long act_cs, float* dx, long dx_cs, int K, int B,
-                                 int In, int Out, hipStream_t stream) {
+                                 int In, int Out, int prec, hipStream_t stream) {
     if (K <= 0 || B <= 0 || In <= 0 || Out <= 0) return -1;
     // dy rows of e.g. 10 classes are not 16-B aligned: element loads then
     const int vec = !((Out & 3) || (dy_cs & 3) || ((uintptr_t)dy & 15));
     DgradArgs a{dy, dy_cs, w, w_cs, act, act_cs, dx, dx_cs, B, In, Out, vec};
     dim3 grid(cdiv(In, 128), cdiv(B, 32), K);
     const bool sparse_grid = (long)grid.x * grid.y * grid.z <= num_cus() && getenv("P2PFL_NO_BK128") == nullptr;
-    if (Out >= 1024 && sparse_grid) hipLaunchKernelGGL((linear_dgrad_kernel<128, 2>), grid, dim3(256), 0, stream, a);
-    else if (Out >= 1024) hipLaunchKernelGGL((linear_dgrad_kernel<64, 2>), grid, dim3(256), 0, stream, a);   // 498 -> 478 us
-    else hipLaunchKernelGGL((linear_dgrad_kernel<32, 2>), grid, dim3(256), 0, stream, a);
+    if (prec == PREC_F32) {
+        if (Out >= 1024 && sparse_grid) hipLaunchKernelGGL((linear_dgrad_kernel<64, 2, float>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((linear_dgrad_kernel<32, 2, float>), grid, dim3(256), 0, stream, a);
+    }
+    else if (Out >= 1024 && sparse_grid) hipLaunchKernelGGL((linear_dgrad_kernel<128, 2, __bf16>), grid, dim3(256), 0, stream, a);
+    else if (Out >= 1024) hipLaunchKernelGGL((linear_dgrad_kernel<64, 2, __bf16>), grid, dim3(256), 0, stream, a);   // 498 -> 478 us
+    else hipLaunchKernelGGL((linear_dgrad_kernel<32, 2, __bf16>), grid, dim3(256), 0, stream, a);
     P2PFL_RETURN_LAST_ERROR();
 }
 
 P2PFL_API int p2pfl_linear_wgrad(const float* dy, long dy_cs, const float* x, long x_cs, float* dw,
                                  long dw_cs, float* db, long db_cs, int K, int B, int In, int Out,
-                                 const int* sidx, long s_cs, hipStream_t stream) {
+                                 const int* sidx, long s_cs, int prec, hipStream_t stream) {
     if (K <= 0 || B <= 0 || In <= 0 || Out <= 0) return -1;
     WgradArgs a{dy, dy_cs, x, x_cs, dw, dw_cs, db, db_cs, B, In, Out, sidx, s_cs};
     dim3 grid(cdiv(In + 1, 128), cdiv(Out, 128), K);
-    hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(256), 0, stream, a);
+    if (prec == PREC_F32) hipLaunchKernelGGL(linear_wgrad_kernel<float>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(linear_wgrad_kernel<__bf16>, grid, dim3(256), 0, stream, a);
     P2PFL_RETURN_LAST_ERROR();
 }

@@ -49,21 +49,77 @@ def available() -> bool:
 
 P, L, I, F = c_void_p, c_long, c_int, c_float
 
+# Precision policy of the matrix products (see csrc/common.h): "fp32" keeps the operands in fp32
+# (v_mfma_f32_32x32x2_f32, exact fp32 fma chains - the reference trains 32-bit,
+# fedstellar/learning/pytorch/lightninglearner.py:182-193), "bf16" rounds them to bf16 with fp32 accumulation
+# (16x the matrix-core rate; a labelled fast mode). Every product wrapper takes ``prec`` (name or None = default).
+PRECISIONS = {"bf16": 0, "fp32": 1}
+_default_prec = "fp32"
+
+
+def set_default_precision(name: str) -> None:
+    global _default_prec
+    if name not in PRECISIONS:
+        raise ValueError(f"unknown precision {name!r}: expected one of {sorted(PRECISIONS)}")
+    _default_prec = name
+
+
+def default_precision() -> str:
+    return _default_prec
+
+
+_PRODUCT_OPS = frozenset((
+    "linear_fwd", "linear_dgrad", "linear_wgrad", "linear_wgrad_adam", "linear_wgrad_sgdm", "conv1_fwd", "conv1_wgrad",
+    "conv2_prep_alloc", "conv2_prep", "conv2_fwd", "conv2_wgrad_scratch", "conv2_wgrad", "conv2_dgrad"))
+
+
+class _Bound:
+    """This module with ``prec`` pre-set on every matrix-product wrapper (what an engine holds)."""
+
+    def __init__(self, prec: str):
+        _prec(prec)
+        self.precision = prec
+        self._cache = {}
+
+    def __getattr__(self, name):
+        import functools
+        import sys
+        fn = self._cache.get(name)
+        if fn is None:
+            fn = getattr(sys.modules[__name__], name)
+            if name in _PRODUCT_OPS:
+                fn = functools.partial(fn, prec=self.precision)
+            self._cache[name] = fn
+        return fn
+
+
+def bound(prec=None) -> "_Bound":
+    return _Bound(_default_prec if prec is None else prec)
+
+
+def _prec(prec) -> int:
+    if prec is None:
+        prec = _default_prec
+    try:
+        return PRECISIONS[prec]
+    except KeyError:
+        raise ValueError(f"unknown precision {prec!r}: expected one of {sorted(PRECISIONS)}") from None
+
 
 class _Sig:
-    p2pfl_linear_fwd = [P, L, P, L, P, L, P, L, I, I, I, I, I, P, L, P, L, P]
+    p2pfl_linear_fwd = [P, L, P, L, P, L, P, L, I, I, I, I, I, P, L, P, L, I, P]
     p2pfl_linear_fwd_scratch = [I, I, I, I]
-    p2pfl_linear_dgrad = [P, L, P, L, P, L, P, L, I, I, I, I, P]
-    p2pfl_linear_wgrad = [P, L, P, L, P, L, P, L, I, I, I, I, P, L, P]
-    p2pfl_linear_wgrad_adam = [P, L, P, L, P, P, P, L, P, P, P, L, I, I, I, I, F, F, F, F, F, I, P, I, P, L, P]
-    p2pfl_linear_wgrad_sgdm = [P, L, P, L, P, P, L, P, P, L, I, I, I, I, F, F, F, I, P, L, P]
-    p2pfl_conv1_fwd = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, P]
-    p2pfl_conv1_wgrad = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, P]
-    p2pfl_conv2_prep = [P, L, P, L, I, I, I, I, P]
-    p2pfl_conv2_fwd = [P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, P]
-    p2pfl_conv2_wgrad = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, P]
-    p2pfl_conv2_wgrad_scratch = [I, I, I]
-    p2pfl_conv2_dgrad = [P, L, P, L, P, L, P, L, I, I, I, I, I, P]
+    p2pfl_linear_dgrad = [P, L, P, L, P, L, P, L, I, I, I, I, I, P]
+    p2pfl_linear_wgrad = [P, L, P, L, P, L, P, L, I, I, I, I, P, L, I, P]
+    p2pfl_linear_wgrad_adam = [P, L, P, L, P, P, P, L, P, P, P, L, I, I, I, I, F, F, F, F, F, I, P, I, P, L, I, P]
+    p2pfl_linear_wgrad_sgdm = [P, L, P, L, P, P, L, P, P, L, I, I, I, I, F, F, F, I, P, L, I, P]
+    p2pfl_conv1_fwd = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, P]
+    p2pfl_conv1_wgrad = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, P]
+    p2pfl_conv2_prep = [P, L, P, L, I, I, I, I, I, P]
+    p2pfl_conv2_fwd = [P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, I, P]
+    p2pfl_conv2_wgrad = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, I, P]
+    p2pfl_conv2_wgrad_scratch = [I, I, I, I]
+    p2pfl_conv2_dgrad = [P, L, P, L, P, L, P, L, I, I, I, I, I, I, P]
     p2pfl_softmax_ce = [P, L, P, L, P, L, P, L, P, P, P, P, P, L, I, I, I, P]
     p2pfl_zero_rows = [P, L, I, I, P]
     p2pfl_adam_step = [P, P, P, P, L, L, I, F, F, F, F, F, I, P, P]
@@ -114,7 +170,7 @@ def linear_fwd_scratch(K: int, B: int, In: int, Out: int, device) -> Optional[to
     return torch.empty(need, dtype=torch.float32, device=device) if need else None
 
 
-def linear_fwd(x, w, b, y, relu: bool, sidx=None, scratch: Optional[torch.Tensor] = None) -> None:
+def linear_fwd(x, w, b, y, relu: bool, sidx=None, scratch: Optional[torch.Tensor] = None, prec=None) -> None:
     """y[k] = act(x[k] @ w[k].T + b[k]);  x [K,B,In], w [K,Out,In], b [K,Out], y [K,B,Out].
 
     ``sidx`` [K,B] int32: x is the whole data set [K,n,In] and row r of the product is x[k, sidx[k, r]] (the
@@ -138,31 +194,32 @@ def linear_fwd(x, w, b, y, relu: bool, sidx=None, scratch: Optional[torch.Tensor
             if buf is None or buf.numel() < need:
                 buf = _fwd_scratch[key] = torch.empty(need, dtype=torch.float32, device=y.device)
         cp = buf.data_ptr()
-    _chk(lib.p2pfl_linear_fwd(xp, xs, wp, ws, bp, bs, yp, ys, K, B, In, Out, int(relu), sp, ss, cp, need, stream),
-         "linear_fwd")
+    _chk(lib.p2pfl_linear_fwd(xp, xs, wp, ws, bp, bs, yp, ys, K, B, In, Out, int(relu), sp, ss, cp, need,
+                              _prec(prec), stream), "linear_fwd")
 
 
-def linear_dgrad(dy, w, act, dx) -> None:
+def linear_dgrad(dy, w, act, dx, prec=None) -> None:
     """dx[k] = (dy[k] @ w[k]) * (act[k] > 0)   (act None: no mask)."""
     K, B, Out = dy.shape
     In = w.shape[2]
     assert w.shape == (K, Out, In) and dx.shape == (K, B, In)
     (dp, ds), (wp, ws), (ap, as_), (xp, xs) = _pc(dy), _pc(w), _pc(act), _pc(dx)
-    _chk(load().p2pfl_linear_dgrad(dp, ds, wp, ws, ap, as_, xp, xs, K, B, In, Out, _stream()), "linear_dgrad")
+    _chk(load().p2pfl_linear_dgrad(dp, ds, wp, ws, ap, as_, xp, xs, K, B, In, Out, _prec(prec), _stream()),
+         "linear_dgrad")
 
 
-def linear_wgrad(dy, x, dw, db, sidx=None) -> None:
+def linear_wgrad(dy, x, dw, db, sidx=None, prec=None) -> None:
     """dw[k] = dy[k].T @ x[k];  db[k] = dy[k].sum(0).   (``sidx``: batch rows gathered from x, see linear_fwd)"""
     K, B, Out = dy.shape
     In = x.shape[2]
     assert dw.shape == (K, Out, In) and db.shape == (K, Out) and (sidx is None or sidx.shape == (K, B))
     (dp, ds), (xp, xs), (wp, ws), (bp, bs), (sp, ss) = _pc(dy), _pc(x), _pc(dw), _pc(db), _pc(sidx, torch.int32)
-    _chk(load().p2pfl_linear_wgrad(dp, ds, xp, xs, wp, ws, bp, bs, K, B, In, Out, sp, ss, _stream()),
+    _chk(load().p2pfl_linear_wgrad(dp, ds, xp, xs, wp, ws, bp, bs, K, B, In, Out, sp, ss, _prec(prec), _stream()),
          "linear_wgrad")
 
 
 def linear_wgrad_adam(dy, x, w, mw, vw, b, mb, vb, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
-                      t: int, bc=None, fresh: bool = False, sidx=None) -> None:
+                      t: int, bc=None, fresh: bool = False, sidx=None, prec=None) -> None:
     """Fused ``dw = dy.T @ x`` + Adam update of (w, b) and their moments; the gradient is never
     written to memory. w/mw/vw are [K,Out,In] slab views with one common row stride, b/mb/vb [K,Out].
     ``fresh``: first step of a new optimizer - the moments count as zero and are not read (only written)."""
@@ -174,12 +231,12 @@ def linear_wgrad_adam(dy, x, w, mw, vw, b, mb, vb, *, lr, beta1=0.9, beta2=0.999
     _chk(load().p2pfl_linear_wgrad_adam(dp, ds, xp, xs, _t(w).data_ptr(), _t(mw).data_ptr(), _t(vw).data_ptr(),
                                         w.stride(0), _t(b).data_ptr(), _t(mb).data_ptr(), _t(vb).data_ptr(),
                                         b.stride(0), K, B, In, Out, lr, beta1, beta2, eps, weight_decay, t,
-                                        None if bc is None else _t(bc).data_ptr(), int(fresh), sp, ss, _stream()),
-         "linear_wgrad_adam")
+                                        None if bc is None else _t(bc).data_ptr(), int(fresh), sp, ss, _prec(prec),
+                                        _stream()), "linear_wgrad_adam")
 
 
 def linear_wgrad_sgdm(dy, x, w, mw, b, mb, *, lr, momentum=0.9, weight_decay=0.0, fresh: bool = False,
-                      sidx=None) -> None:
+                      sidx=None, prec=None) -> None:
     """Fused ``dw = dy.T @ x`` + SGD-momentum update of (w, b) and their momentum buffers (same layout rules
     as :func:`linear_wgrad_adam`)."""
     K, B, Out = dy.shape
@@ -189,11 +246,12 @@ def linear_wgrad_sgdm(dy, x, w, mw, b, mb, *, lr, momentum=0.9, weight_decay=0.0
     (dp, ds), (xp, xs), (sp, ss) = _pc(dy), _pc(x), _pc(sidx, torch.int32)
     _chk(load().p2pfl_linear_wgrad_sgdm(dp, ds, xp, xs, _t(w).data_ptr(), _t(mw).data_ptr(), w.stride(0),
                                         _t(b).data_ptr(), _t(mb).data_ptr(), b.stride(0), K, B, In, Out, lr,
-                                        momentum, weight_decay, int(fresh), sp, ss, _stream()), "linear_wgrad_sgdm")
+                                        momentum, weight_decay, int(fresh), sp, ss, _prec(prec), _stream()),
+         "linear_wgrad_sgdm")
 
 
 # ----------------------------------------------------------------------------- conv
-def conv1_fwd(data, sidx, w, bias, a1, code, ks: int) -> None:
+def conv1_fwd(data, sidx, w, bias, a1, code, ks: int, prec=None) -> None:
     """Stage-1 conv(1->F, ks x ks, same) + ReLU + 2x2 maxpool.
 
     data [K,n,784] fp32, sidx [K,B] int32 or None, w [K,F,ks*ks], bias [K,F],
@@ -202,36 +260,40 @@ def conv1_fwd(data, sidx, w, bias, a1, code, ks: int) -> None:
     K, B, Fm = a1.shape[0], a1.shape[1], a1.shape[2]
     (dp, ds), (sp, ss), (wp, ws), (bp, bs), (ap, as_) = _pc(data), _pc(sidx, torch.int32), _pc(w), _pc(bias), _pc(a1)
     cp, cs = _pc(code, torch.uint8)
-    _chk(load().p2pfl_conv1_fwd(dp, ds, sp, ss, wp, ws, bp, bs, ap, as_, cp, cs, K, B, Fm, ks, _stream()),
+    _chk(load().p2pfl_conv1_fwd(dp, ds, sp, ss, wp, ws, bp, bs, ap, as_, cp, cs, K, B, Fm, ks, _prec(prec), _stream()),
          "conv1_fwd")
 
 
-def conv1_wgrad(g, code, data, sidx, dw, db, ks: int) -> None:
+def conv1_wgrad(g, code, data, sidx, dw, db, ks: int, prec=None) -> None:
     """Stage-1 weight/bias gradient (dw/db are zeroed here, then accumulated with atomics)."""
     K, B, Fm = g.shape[0], g.shape[1], g.shape[2]
     zero_rows(dw)
     zero_rows(db)
     (gp, gs), (dp, ds), (sp, ss), (wp, ws), (bp, bs) = _pc(g), _pc(data), _pc(sidx, torch.int32), _pc(dw), _pc(db)
     cp, cs = _pc(code, torch.uint8)
-    _chk(load().p2pfl_conv1_wgrad(gp, gs, cp, cs, dp, ds, sp, ss, wp, ws, bp, bs, K, B, Fm, ks, _stream()),
-         "conv1_wgrad")
+    _chk(load().p2pfl_conv1_wgrad(gp, gs, cp, cs, dp, ds, sp, ss, wp, ws, bp, bs, K, B, Fm, ks, _prec(prec),
+                                  _stream()), "conv1_wgrad")
 
 
-def conv2_prep_alloc(K: int, ks: int, device) -> torch.Tensor:
-    """Workspace of :func:`conv2_prep`: per client a tap-major bf16 copy of the stage-2 weights for the
-    forward pass followed by the mirrored, transposed copy for the data gradient."""
-    return torch.empty(K, 2 * ks * ks * 64 * 32, dtype=torch.bfloat16, device=device)
+def _prep_dtype(prec):
+    return torch.float32 if _prec(prec) == PRECISIONS["fp32"] else torch.bfloat16
 
 
-def conv2_prep(w, wprep, ks: int) -> None:
+def conv2_prep_alloc(K: int, ks: int, device, prec=None) -> torch.Tensor:
+    """Workspace of :func:`conv2_prep`: per client a tap-major copy (fp32 or bf16, by ``prec``) of the stage-2
+    weights for the forward pass followed by the mirrored, transposed copy for the data gradient."""
+    return torch.empty(K, 2 * ks * ks * 64 * 32, dtype=_prep_dtype(prec), device=device)
+
+
+def conv2_prep(w, wprep, ks: int, prec=None) -> None:
     """w [K,Cout=64,Cin*ks*ks] fp32 -> wprep (see conv2_prep_alloc). Run once per weight update."""
     K, Cout = w.shape[0], w.shape[1]
     Cin = w.shape[2] // (ks * ks)
-    (wp, ws), (pp, ps) = _pc(w), _pc(wprep, torch.bfloat16)
-    _chk(load().p2pfl_conv2_prep(wp, ws, pp, ps, K, Cin, Cout, ks, _stream()), "conv2_prep")
+    (wp, ws), (pp, ps) = _pc(w), _pc(wprep, _prep_dtype(prec))
+    _chk(load().p2pfl_conv2_prep(wp, ws, pp, ps, K, Cin, Cout, ks, _prec(prec), _stream()), "conv2_prep")
 
 
-def conv2_fwd(a1, w, bias, a2, code, ks: int, wprep=None) -> None:
+def conv2_fwd(a1, w, bias, a2, code, ks: int, wprep=None, prec=None) -> None:
     """Stage-2 conv(Cin->Cout, ks x ks, same) + ReLU + 2x2 maxpool on the matrix cores.
 
     a1 [K,B,Cin,196], w [K,Cout,Cin*ks*ks], bias [K,Cout], a2 [K,B,Cout,49], code uint8 like a2.
@@ -240,25 +302,25 @@ def conv2_fwd(a1, w, bias, a2, code, ks: int, wprep=None) -> None:
     K, B, Cin = a1.shape[0], a1.shape[1], a1.shape[2]
     Cout = w.shape[1]
     if wprep is None:
-        wprep = conv2_prep_alloc(K, ks, a1.device)
-        conv2_prep(w, wprep, ks)
-    (ap, as_), (pp, ps), (bp, bs), (op, os_) = _pc(a1), _pc(wprep, torch.bfloat16), _pc(bias), _pc(a2)
+        wprep = conv2_prep_alloc(K, ks, a1.device, prec)
+        conv2_prep(w, wprep, ks, prec)
+    (ap, as_), (pp, ps), (bp, bs), (op, os_) = _pc(a1), _pc(wprep, _prep_dtype(prec)), _pc(bias), _pc(a2)
     cp, cs = _pc(code, torch.uint8)
-    _chk(load().p2pfl_conv2_fwd(ap, as_, pp, ps, bp, bs, op, os_, cp, cs, K, B, Cin, Cout, ks, _stream()),
-         "conv2_fwd")
+    _chk(load().p2pfl_conv2_fwd(ap, as_, pp, ps, bp, bs, op, os_, cp, cs, K, B, Cin, Cout, ks, _prec(prec),
+                                _stream()), "conv2_fwd")
 
 
 _wgrad_scratch = {}
 
 
-def conv2_wgrad_scratch(K: int, B: int, ks: int, device) -> Optional[torch.Tensor]:
+def conv2_wgrad_scratch(K: int, B: int, ks: int, device, prec=None) -> Optional[torch.Tensor]:
     """Scratch buffer :func:`conv2_wgrad` wants for this problem size (None: it needs none). With few clients
     the batch is split over more blocks and their partial sums go through this buffer."""
-    need = int(load().p2pfl_conv2_wgrad_scratch(K, B, ks))
+    need = int(load().p2pfl_conv2_wgrad_scratch(K, B, ks, _prec(prec)))
     return torch.empty(need, dtype=torch.float32, device=device) if need else None
 
 
-def conv2_wgrad(g, code, a1, dw, db, ks: int, scratch: Optional[torch.Tensor] = None) -> None:
+def conv2_wgrad(g, code, a1, dw, db, ks: int, scratch: Optional[torch.Tensor] = None, prec=None) -> None:
     """Stage-2 weight/bias gradient: dw [K,Cout,Cin*ks*ks], db [K,Cout] (overwritten).
 
     ``scratch``: buffer from :func:`conv2_wgrad_scratch` owned by the caller (one call in flight per buffer);
@@ -269,30 +331,31 @@ def conv2_wgrad(g, code, a1, dw, db, ks: int, scratch: Optional[torch.Tensor] = 
     cp, cs = _pc(code, torch.uint8)
     lib = load()
     stream = _stream()
-    need = int(lib.p2pfl_conv2_wgrad_scratch(K, B, ks))
+    need = int(lib.p2pfl_conv2_wgrad_scratch(K, B, ks, _prec(prec)))
     sp = 0
     if need:
         if scratch is not None and scratch.numel() >= need:
             buf = _t(scratch)
         else:
-            key = (g.device, int(stream or 0), threading.get_ident())
+            key = (g.device, int(stream or 0), threading.get_ident(), _prec(prec))
             buf = _wgrad_scratch.get(key)
             if buf is None or buf.numel() < need:
                 buf = _wgrad_scratch[key] = torch.empty(need, dtype=torch.float32, device=g.device)
         sp = buf.data_ptr()
-    _chk(lib.p2pfl_conv2_wgrad(gp, gs, cp, cs, ap, as_, wp, ws, bp, bs, sp, need, K, B, Cin, Cout, ks, stream),
-         "conv2_wgrad")
+    _chk(lib.p2pfl_conv2_wgrad(gp, gs, cp, cs, ap, as_, wp, ws, bp, bs, sp, need, K, B, Cin, Cout, ks, _prec(prec),
+                               stream), "conv2_wgrad")
 
 
-def conv2_dgrad(g, code, w, da1, ks: int, wprep=None) -> None:
+def conv2_dgrad(g, code, w, da1, ks: int, wprep=None, prec=None) -> None:
     K, B, Cout = g.shape[0], g.shape[1], g.shape[2]
     Cin = da1.shape[2]
     if wprep is None:
-        wprep = conv2_prep_alloc(K, ks, g.device)
-        conv2_prep(w, wprep, ks)
-    (gp, gs), (pp, ps), (dp, ds) = _pc(g), _pc(wprep, torch.bfloat16), _pc(da1)
+        wprep = conv2_prep_alloc(K, ks, g.device, prec)
+        conv2_prep(w, wprep, ks, prec)
+    (gp, gs), (pp, ps), (dp, ds) = _pc(g), _pc(wprep, _prep_dtype(prec)), _pc(da1)
     cp, cs = _pc(code, torch.uint8)
-    _chk(load().p2pfl_conv2_dgrad(gp, gs, cp, cs, pp, ps, dp, ds, K, B, Cin, Cout, ks, _stream()), "conv2_dgrad")
+    _chk(load().p2pfl_conv2_dgrad(gp, gs, cp, cs, pp, ps, dp, ds, K, B, Cin, Cout, ks, _prec(prec), _stream()),
+         "conv2_dgrad")
 
 
 # ----------------------------------------------------------------------------- loss / misc

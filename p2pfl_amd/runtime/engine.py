@@ -268,13 +268,17 @@ def live_aux_streams():
 class HipEngine(ShardEngine):
     """Client-batched gfx950 kernels + hipGraph replay (see module docstring)."""
 
-    def __init__(self, *a, use_graph: bool = True, fuse_optimizer: bool = True, overlap: bool = True, **kw):
+    def __init__(self, *a, use_graph: bool = True, fuse_optimizer: bool = True, overlap: bool = True,
+                 precision: Optional[str] = None, **kw):
         super().__init__(*a, **kw)
         if self.device.type != "cuda":
             raise RuntimeError("HipEngine needs a GPU device")
         from ..ops import hip
         hip.load()   # fail loudly if the kernels were not built
-        self.hip = hip
+        # precision policy of every matrix product of this engine: "fp32" (default; the reference trains 32-bit,
+        # fedstellar/learning/pytorch/lightninglearner.py:182-193) or "bf16" (bf16 operands, fp32 accumulation)
+        self.precision = precision or os.environ.get("P2PFL_PRECISION") or hip.default_precision()
+        self.hip = hip = hip.bound(self.precision)
         self.use_graph = use_graph
         K, B, L = self.K, self.B, self.layout
         dev = self.device
@@ -289,7 +293,7 @@ class HipEngine(ShardEngine):
         # dense layer streams its weights once per up to EVAL_B rows instead of once per 32
         self._eval_bufs: Dict[int, tuple] = {}
         self._fwd_scratch: Dict[tuple, Optional[torch.Tensor]] = {}
-        # tap-major bf16 weight copies of the stage-2 convolutions (refreshed at every forward pass)
+        # tap-major weight copies (in the engine's precision) of the stage-2 convolutions (refreshed at every forward pass)
         self.wprep = {i: hip.conv2_prep_alloc(K, l.ksize, dev) for i, l in enumerate(self.spec.layers)
                       if l.kind == "conv2pool"}
         # partial-sum scratch of the batch-split stage-2 weight gradient (small shards only)
@@ -768,6 +772,7 @@ def make_engine(spec: ModelSpec, n_clients: int, device, impl: str = "auto", **k
         from .module_engine import ModuleEngine
         kw.pop("use_graph", None)
         kw.pop("overlap", None)
+        kw.pop("precision", None)
         return ModuleEngine(spec, n_clients, device, **kw)
     if impl == "auto":
         impl = "hip" if device.type == "cuda" else "eager"
@@ -775,4 +780,5 @@ def make_engine(spec: ModelSpec, n_clients: int, device, impl: str = "auto", **k
         return HipEngine(spec, n_clients, device, **kw)
     kw.pop("use_graph", None)
     kw.pop("overlap", None)
+    kw.pop("precision", None)      # the eager engine is fp32 by construction
     return EagerEngine(spec, n_clients, device, **kw)

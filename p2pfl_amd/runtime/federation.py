@@ -62,7 +62,7 @@ class BatchedFederation:
                  rank: int = 0, world_size: int = 1, process_group=None, encrypt: bool = False,
                  scenario: str = "scenario", persist_optimizer: bool = False, use_graph: bool = True,
                  overlap: bool = True, heartbeat_period: float = 4.0, node_timeout: float = 20.0,
-                 instant_detection: bool = True):
+                 instant_detection: bool = True, precision: Optional[str] = None):
         self.spec = spec
         self.adj = np.asarray(topology, dtype=np.float32)
         self.N = self.adj.shape[0]
@@ -83,7 +83,8 @@ class BatchedFederation:
         self.engine: ShardEngine = make_engine(spec, self.n_local, self.device, impl=engine, batch_size=batch_size,
                                                seed=seed, persist_optimizer=persist_optimizer,
                                                client_offset=self.local.start,
-                                               **({"use_graph": use_graph, "overlap": overlap} if engine != "eager" else {}))
+                                               **({"use_graph": use_graph, "overlap": overlap, "precision": precision}
+                                                  if engine != "eager" else {}))
         # membership of ALL nodes of the scenario (every rank applies the same deterministic schedule)
         self.membership = VirtualMembership(self.N, heartbeat_period, node_timeout, instant=instant_detection)
         self.alive = np.ones(self.N, dtype=bool)

@@ -1,8 +1,10 @@
 """Numerics of every gfx950 kernel against a plain PyTorch fp32 reference of the same op.
 
-Matrix-core kernels round their operands to bf16 (fp32 accumulate), so they are compared with
-a bf16-appropriate tolerance; VALU kernels (conv1 forward, CE, optimizers, FedAvg, AES) must
-match to fp32 round-off / exactly.
+Every matrix-core kernel exists in two precisions (``prec`` fixture): "fp32" (v_mfma_f32_32x32x2_f32, exact fp32
+fma chains - the default and the reference's precision) must match the fp32 reference to round-off
+(max-normalised error <= 2e-5 dense, <= 2e-4 convolutions: MIOpen's own fp32 algorithms differ by that much);
+"bf16" rounds the operands to bf16 (fp32 accumulate) and is compared with a bf16-appropriate tolerance.
+VALU kernels (CE, optimizers, FedAvg, AES) must match to fp32 round-off / exactly.
 """
 import pytest
 import torch
@@ -17,6 +19,20 @@ def hip():
     from p2pfl_amd.ops import hip as h
     h.load()
     return h
+
+
+@pytest.fixture(params=["fp32", "bf16"])
+def prec(request):
+    """Runs the test once per precision policy, as the default of every product wrapper."""
+    from p2pfl_amd.ops import hip as h
+    old = h.default_precision()
+    h.set_default_precision(request.param)
+    yield request.param
+    h.set_default_precision(old)
+
+
+TOL_DENSE = {"fp32": 2e-5, "bf16": 2e-2}
+TOL_CONV = {"fp32": 2e-4, "bf16": 2e-2}
 
 
 def rel_err(a, b):
@@ -52,7 +68,7 @@ def route(g, code, P):
                                              # reduction split over blocks (few clients): 8 / 4 / 2 splits
                                              (10, 32, 2048, 10, False), (50, 32, 3136, 62, False),
                                              (100, 32, 2048, 10, True), (3, 70, 3137, 62, True)])
-def test_linear_fwd(K, B, In, Out, relu):
+def test_linear_fwd(K, B, In, Out, relu, prec):
     h = hip()
     x = torch.randn(K, B, In, device=DEV)
     w = slab_view(K, (Out, In)) * 0.05
@@ -62,12 +78,12 @@ def test_linear_fwd(K, B, In, Out, relu):
     ref = torch.baddbmm(b.unsqueeze(1), x, w.transpose(1, 2))
     if relu:
         ref = ref.relu()
-    assert rel_err(y, ref) < 2e-2
+    assert rel_err(y, ref) < TOL_DENSE[prec]
 
 
 @pytest.mark.parametrize("K,B,In,Out,mask", [(3, 32, 256, 128, True), (2, 32, 2048, 10, True),
                                              (2, 28, 3136, 2048, False), (1, 7, 50, 6, False)])
-def test_linear_dgrad(K, B, In, Out, mask):
+def test_linear_dgrad(K, B, In, Out, mask, prec):
     h = hip()
     dy = torch.randn(K, B, Out, device=DEV)
     w = slab_view(K, (Out, In)) * 0.05
@@ -77,23 +93,23 @@ def test_linear_dgrad(K, B, In, Out, mask):
     ref = torch.bmm(dy, w)
     if mask:
         ref = ref * (act > 0)
-    assert rel_err(dx, ref) < 2e-2
+    assert rel_err(dx, ref) < TOL_DENSE[prec]
 
 
 @pytest.mark.parametrize("K,B,In,Out", [(3, 32, 784, 256), (2, 32, 2048, 10), (2, 17, 3136, 70), (1, 40, 33, 5)])
-def test_linear_wgrad(K, B, In, Out):
+def test_linear_wgrad(K, B, In, Out, prec):
     h = hip()
     dy = torch.randn(K, B, Out, device=DEV)
     x = torch.randn(K, B, In, device=DEV)
     dw = slab_view(K, (Out, In))
     db = slab_view(K, (Out,))
     h.linear_wgrad(dy, x, dw, db)
-    assert rel_err(dw, torch.bmm(dy.transpose(1, 2), x)) < 2e-2
-    assert rel_err(db, dy.sum(1)) < 2e-2
+    assert rel_err(dw, torch.bmm(dy.transpose(1, 2), x)) < TOL_DENSE[prec]
+    assert rel_err(db, dy.sum(1)) < TOL_DENSE[prec]
 
 
 @pytest.mark.parametrize("K,B,In,Out", [(2, 32, 3136, 300), (1, 20, 130, 70)])
-def test_linear_wgrad_adam_matches_unfused(K, B, In, Out):
+def test_linear_wgrad_adam_matches_unfused(K, B, In, Out, prec):
     h = hip()
     P = In * Out + 64 - (In * Out) % 64 + 512
     slabs = [torch.randn(K, P, device=DEV) * 0.05 for _ in range(3)]
@@ -115,7 +131,7 @@ def test_linear_wgrad_adam_matches_unfused(K, B, In, Out):
 
 
 @pytest.mark.parametrize("K,B,n,In,Out", [(3, 32, 100, 784, 256), (2, 20, 57, 130, 10), (2, 32, 64, 2048, 10)])
-def test_linear_gather_of_batch_rows(K, B, n, In, Out):
+def test_linear_gather_of_batch_rows(K, B, n, In, Out, prec):
     """sidx: forward / weight gradient / fused update read the mini-batch rows straight from the data set."""
     h = hip()
     data = torch.randn(K, n, In, device=DEV)
@@ -146,7 +162,7 @@ def test_linear_gather_of_batch_rows(K, B, n, In, Out):
 
 
 @pytest.mark.parametrize("kind", ["adam", "sgd"])
-def test_fused_update_fresh_step_ignores_stale_moments(kind):
+def test_fused_update_fresh_step_ignores_stale_moments(kind, prec):
     """fresh=True (first step of a new optimizer) on garbage moments == the ordinary step on zeroed ones."""
     h = hip()
     K, B, In, Out = 2, 32, 260, 70
@@ -172,7 +188,7 @@ def test_fused_update_fresh_step_ignores_stale_moments(kind):
 
 
 @pytest.mark.parametrize("K,B,In,Out", [(2, 32, 3136, 62), (3, 20, 130, 70), (2, 32, 256, 128)])
-def test_linear_wgrad_sgdm_matches_unfused(K, B, In, Out):
+def test_linear_wgrad_sgdm_matches_unfused(K, B, In, Out, prec):
     """Fused weight gradient + SGD-momentum (with weight decay) == wgrad kernel followed by sgdm_step."""
     h = hip()
     P = In * Out + 64 - (In * Out) % 64 + 512
@@ -196,7 +212,7 @@ def test_linear_wgrad_sgdm_matches_unfused(K, B, In, Out):
 
 
 @pytest.mark.parametrize("ks,B,Fm", [(5, 32, 32), (7, 32, 32), (5, 7, 32), (7, 13, 20)])
-def test_conv1_fwd(ks, B, Fm):
+def test_conv1_fwd(ks, B, Fm, prec):
     h = hip()
     K, n = 3, 40
     data = torch.rand(K, n, 784, device=DEV)
@@ -209,13 +225,14 @@ def test_conv1_fwd(ks, B, Fm):
     assert torch.isfinite(a1).all() and (code <= 4).all()
     for k in range(K):
         xb = data[k][sidx[k].long()].view(B, 1, 28, 28)
-        # matrix-core kernel: operands are rounded to bf16 (fp32 accumulate) -> compare with the same rounding
-        xr, wr = xb.bfloat16().float(), w[k].bfloat16().float()
+        # bf16 mode: operands are rounded to bf16 (fp32 accumulate) -> compare with the same rounding first
+        xr, wr = (xb.bfloat16().float(), w[k].bfloat16().float()) if prec == "bf16" else (xb, w[k])
         pre = F.conv2d(xr, wr.reshape(Fm, 1, ks, ks), b[k], padding=ks // 2)
         ref = F.max_pool2d(pre.relu(), 2, 2).reshape(B, Fm, 196)
-        assert torch.allclose(a1[k], ref, atol=2e-4, rtol=2e-4)
+        assert torch.allclose(a1[k], ref, atol=2e-4, rtol=2e-4) if prec == "bf16" else \
+            torch.allclose(a1[k], ref, atol=2e-5, rtol=2e-5)
         full = F.max_pool2d(F.conv2d(xb, w[k].reshape(Fm, 1, ks, ks), b[k], padding=ks // 2).relu(), 2, 2)
-        assert rel_err(a1[k], full.reshape(B, Fm, 196)) < 2e-2
+        assert rel_err(a1[k], full.reshape(B, Fm, 196)) < TOL_CONV[prec]
         # the code must point at the arg-max (or 4 when the window is <= 0)
         win = pre.reshape(B, Fm, 14, 2, 14, 2).permute(0, 1, 2, 4, 3, 5).reshape(B, Fm, 196, 4)
         c = code[k].long()
@@ -226,7 +243,7 @@ def test_conv1_fwd(ks, B, Fm):
 
 
 @pytest.mark.parametrize("ks,B,Fm,K", [(5, 32, 32, 2), (7, 32, 32, 2), (7, 9, 20, 3), (5, 32, 32, 300)])
-def test_conv1_wgrad(ks, B, Fm, K):
+def test_conv1_wgrad(ks, B, Fm, K, prec):
     h = hip()
     n = 40
     data = torch.rand(K, n, 784, device=DEV)
@@ -240,12 +257,12 @@ def test_conv1_wgrad(ks, B, Fm, K):
     for k in range(K):
         xb = data[k][sidx[k].long()].view(B, 1, 28, 28)
         ref = torch.nn.grad.conv2d_weight(xb, (Fm, 1, ks, ks), dpre[k], padding=ks // 2).reshape(Fm, ks * ks)
-        assert rel_err(dw[k], ref) < 2e-2
-        assert rel_err(db[k], dpre[k].sum(dim=(0, 2, 3))) < 2e-2
+        assert rel_err(dw[k], ref) < TOL_CONV[prec]
+        assert rel_err(db[k], dpre[k].sum(dim=(0, 2, 3))) < TOL_CONV[prec]
 
 
 @pytest.mark.parametrize("ks,B,K", [(5, 32, 2), (3, 32, 2), (5, 9, 3), (5, 32, 11), (3, 7, 9)])
-def test_conv2_fwd(ks, B, K):
+def test_conv2_fwd(ks, B, K, prec):
     h = hip()
     Cin, Cout = 32, 64
     a1 = torch.randn(K, B, Cin, 196, device=DEV).relu()
@@ -257,13 +274,13 @@ def test_conv2_fwd(ks, B, K):
     for k in range(K):
         pre = F.conv2d(a1[k].view(B, Cin, 14, 14), w[k].reshape(Cout, Cin, ks, ks), b[k], padding=ks // 2)
         ref = F.max_pool2d(pre.relu(), 2, 2).reshape(B, Cout, 49)
-        assert rel_err(a2[k], ref) < 2e-2
+        assert rel_err(a2[k], ref) < TOL_CONV[prec]
         assert ((a2[k] == 0) == (code[k] == 4)).all()
 
 
 # K = 2..11: batch-split blocks + partial reduction; K = 60 / 130: one block per (client, tap part)
 @pytest.mark.parametrize("ks,B,K", [(5, 32, 2), (3, 32, 2), (5, 9, 3), (5, 32, 11), (3, 7, 9), (5, 4, 60), (3, 3, 130)])
-def test_conv2_wgrad_dgrad(ks, B, K):
+def test_conv2_wgrad_dgrad(ks, B, K, prec):
     h = hip()
     Cin, Cout = 32, 64
     a1 = torch.randn(K, B, Cin, 196, device=DEV).relu()
@@ -281,9 +298,9 @@ def test_conv2_wgrad_dgrad(ks, B, K):
         wk = w[k].reshape(Cout, Cin, ks, ks)
         ref_w = torch.nn.grad.conv2d_weight(x, wk.shape, dpre[k], padding=ks // 2).reshape(Cout, -1)
         ref_x = torch.nn.grad.conv2d_input(x.shape, wk, dpre[k], padding=ks // 2).reshape(B, Cin, 196)
-        assert rel_err(dw[k], ref_w) < 2e-2
-        assert rel_err(db[k], dpre[k].sum(dim=(0, 2, 3))) < 2e-2
-        assert rel_err(da1[k], ref_x) < 2e-2
+        assert rel_err(dw[k], ref_w) < TOL_CONV[prec]
+        assert rel_err(db[k], dpre[k].sum(dim=(0, 2, 3))) < TOL_CONV[prec]
+        assert rel_err(da1[k], ref_x) < TOL_CONV[prec]
 
 
 @pytest.mark.parametrize("C,B,nv", [(10, 32, 32), (62, 32, 28), (10, 100, 77), (62, 256, 200), (17, 40, 40), (64, 5, 3)])
@@ -398,7 +415,7 @@ def test_aes128_ecb_known_answer_and_roundtrip():
 
 @pytest.mark.parametrize("deep", [True, False])
 @pytest.mark.parametrize("In,Out", [(1024, 96), (1100, 70)])
-def test_linear_long_reduction_variants(In, Out, deep, monkeypatch):
+def test_linear_long_reduction_variants(In, Out, deep, monkeypatch, prec):
     """In / Out >= 1024 dispatch to the 64-deep k-step kernels, or to the 128-deep ones when the grid has at
     most one block per CU (as here; P2PFL_NO_BK128 turns that off) - incl. a ragged last step."""
     from p2pfl_amd.ops import hip
@@ -412,11 +429,69 @@ def test_linear_long_reduction_variants(In, Out, deep, monkeypatch):
     y = torch.empty(K, B, Out, device="cuda")
     hip.linear_fwd(x, w, b, y, False)
     ref = torch.einsum("kbi,koi->kbo", x, w) + b[:, None]
-    assert ((y - ref).norm() / ref.norm()).item() < 6e-3
+    assert ((y - ref).norm() / ref.norm()).item() < (6e-3 if prec == "bf16" else 1e-5)
     # data gradient with the roles of In / Out swapped: the reduction runs over `Out2 = In`
     dy = torch.randn(K, B, In, device="cuda")
     w2 = torch.randn(K, In, Out, device="cuda") * 0.05
     dx = torch.empty(K, B, Out, device="cuda")
     hip.linear_dgrad(dy, w2, None, dx)
     refd = torch.einsum("kbo,koi->kbi", dy, w2)
-    assert ((dx - refd).norm() / refd.norm()).item() < 6e-3
+    assert ((dx - refd).norm() / refd.norm()).item() < (6e-3 if prec == "bf16" else 1e-5)
+
+
+@pytest.mark.parametrize("K,B,In,Out,wd", [(2, 32, 3136, 300, 0.0), (3, 20, 130, 70, 1e-2), (1, 32, 784, 256, 0.0)])
+def test_linear_wgrad_adam_against_torch_optim(K, B, In, Out, wd):
+    """fp32 fused weight gradient + Adam, three steps, directly against torch.optim.Adam fed with dy.T @ x
+    (not against this repo's own unfused kernels)."""
+    h = hip()
+    torch.manual_seed(5)
+    n = In * Out
+    P = n + 64 - n % 64 + 512
+    slabs = [torch.randn(K, P, device=DEV) * 0.05, torch.zeros(K, P, device=DEV), torch.zeros(K, P, device=DEV)]
+    view = lambda s: (s[:, :n].unflatten(1, (Out, In)), s[:, P - 512:P - 512 + Out])
+    (w, b), (mw, mb), (vw, vb) = view(slabs[0]), view(slabs[1]), view(slabs[2])
+    ref_w = [torch.nn.Parameter(w[k].clone()) for k in range(K)]
+    ref_b = [torch.nn.Parameter(b[k].clone()) for k in range(K)]
+    opt = torch.optim.Adam(ref_w + ref_b, lr=1e-3, weight_decay=wd)
+    for t in range(1, 4):
+        dy = torch.randn(K, B, Out, device=DEV) * 0.1
+        x = torch.randn(K, B, In, device=DEV)
+        h.linear_wgrad_adam(dy, x, w, mw, vw, b, mb, vb, lr=1e-3, weight_decay=wd, t=t, fresh=(t == 1), prec="fp32")
+        for k in range(K):
+            ref_w[k].grad = dy[k].T @ x[k]
+            ref_b[k].grad = dy[k].sum(0)
+        opt.step()
+    for k in range(K):
+        # An Adam step is lr * m / (sqrt(v) + eps): gradient round-off (1e-7 relative to a typical gradient) moves it
+        # by ~1e-7 * lr - except for the one-in-a-million weight whose gradient is itself round-off-sized, where the
+        # normalisation turns that into a step of up to lr per step. Everything else must agree to 2e-6.
+        for got, want in ((w[k], ref_w[k].detach()), (b[k], ref_b[k].detach())):
+            diff = (got - want).abs()
+            assert (diff > 2e-6 + 1e-5 * want.abs()).float().mean().item() < 1e-5
+            assert diff.max().item() <= 3 * 2e-3
+
+
+@pytest.mark.parametrize("K,B,In,Out,wd", [(2, 32, 3136, 62, 0.0), (3, 20, 130, 70, 1e-3)])
+def test_linear_wgrad_sgdm_against_torch_optim(K, B, In, Out, wd):
+    """fp32 fused weight gradient + SGD-momentum directly against torch.optim.SGD on dy.T @ x."""
+    h = hip()
+    torch.manual_seed(6)
+    n = In * Out
+    P = n + 64 - n % 64 + 512
+    slabs = [torch.randn(K, P, device=DEV) * 0.05, torch.zeros(K, P, device=DEV)]
+    view = lambda s: (s[:, :n].unflatten(1, (Out, In)), s[:, P - 512:P - 512 + Out])
+    (w, b), (mw, mb) = view(slabs[0]), view(slabs[1])
+    ref_w = [torch.nn.Parameter(w[k].clone()) for k in range(K)]
+    ref_b = [torch.nn.Parameter(b[k].clone()) for k in range(K)]
+    opt = torch.optim.SGD(ref_w + ref_b, lr=1e-2, momentum=0.9, weight_decay=wd)
+    for t in range(1, 4):
+        dy = torch.randn(K, B, Out, device=DEV) * 0.1
+        x = torch.randn(K, B, In, device=DEV)
+        h.linear_wgrad_sgdm(dy, x, w, mw, b, mb, lr=1e-2, momentum=0.9, weight_decay=wd, fresh=(t == 1), prec="fp32")
+        for k in range(K):
+            ref_w[k].grad = dy[k].T @ x[k]
+            ref_b[k].grad = dy[k].sum(0)
+        opt.step()
+    for k in range(K):
+        assert torch.allclose(w[k], ref_w[k].detach(), atol=1e-6, rtol=1e-5)
+        assert torch.allclose(b[k], ref_b[k].detach(), atol=1e-6, rtol=1e-5)

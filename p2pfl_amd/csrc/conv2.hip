@@ -577,10 +577,11 @@ P2PFL_API int p2pfl_conv2_prep(const float* w, long w_cs, void* wp, long wp_cs, 
 
 P2PFL_API int p2pfl_conv2_fwd(const float* a1, long a1_cs, const void* wp, long wp_cs, const float* bias,
                               long b_cs, float* a2, long a2_cs, uint8_t* code, long c_cs, int K, int B,
-                              int CIN_, int COUT_, int KS, int prec, hipStream_t stream) {
+                              int CIN_, int COUT_, int KS, int prec, int flags, hipStream_t stream) {
     if (K <= 0 || B <= 0 || CIN_ != CIN || COUT_ != COUT) return -1;
     if (prec == PREC_F32)
-        return conv2_fwd_f32(a1, a1_cs, (const float*)wp, wp_cs, bias, b_cs, a2, a2_cs, code, c_cs, K, B, KS, stream);
+        return conv2_fwd_f32(a1, a1_cs, (const float*)wp, wp_cs, bias, b_cs, a2, a2_cs, code, c_cs, K, B, KS, flags,
+                             stream);
     if ((wp_cs & 7) || ((uintptr_t)wp & 15)) return -2;
     if (((uintptr_t)a2 & 15) || (a2_cs & 3) || ((uintptr_t)code & 15) || (c_cs & 15)) return -2;   // 16-byte block stores
     FwdArgs a{a1, a1_cs, (const __bf16*)wp, wp_cs, bias, b_cs, a2, a2_cs, code, c_cs, K, B};
@@ -593,10 +594,10 @@ P2PFL_API int p2pfl_conv2_fwd(const float* a1, long a1_cs, const void* wp, long 
 
 P2PFL_API int p2pfl_conv2_dgrad(const float* g, long g_cs, const uint8_t* code, long c_cs, const void* wp,
                                 long wp_cs, float* da1, long da1_cs, int K, int B, int CIN_, int COUT_,
-                                int KS, int prec, hipStream_t stream) {
+                                int KS, int prec, int flags, hipStream_t stream) {
     if (K <= 0 || B <= 0 || CIN_ != CIN || COUT_ != COUT) return -1;
     if (prec == PREC_F32)
-        return conv2_dgrad_f32(g, g_cs, code, c_cs, (const float*)wp, wp_cs, da1, da1_cs, K, B, KS, stream);
+        return conv2_dgrad_f32(g, g_cs, code, c_cs, (const float*)wp, wp_cs, da1, da1_cs, K, B, KS, flags, stream);
     if ((wp_cs & 7) || ((uintptr_t)wp & 15) || (da1_cs & 3) || ((uintptr_t)da1 & 15)) return -2;
     DgradArgs a{g, g_cs, code, c_cs, (const __bf16*)wp, wp_cs, da1, da1_cs, K, B};
     dim3 grid(cdiv(K, 8) * 8 * B);
@@ -659,11 +660,11 @@ P2PFL_API long p2pfl_conv2_wgrad_scratch(int K, int B, int KS, int prec) {
 P2PFL_API int p2pfl_conv2_wgrad(const float* g, long g_cs, const uint8_t* code, long c_cs, const float* a1,
                                 long a1_cs, float* dw, long dw_cs, float* db, long db_cs, float* scratch,
                                 long scratch_floats, int K, int B, int CIN_, int COUT_, int KS, int prec,
-                                hipStream_t stream) {
+                                int flags, hipStream_t stream) {
     if (K <= 0 || B <= 0 || CIN_ != CIN || COUT_ != COUT) return -1;
     if (prec == PREC_F32)
         return conv2_wgrad_f32(g, g_cs, code, c_cs, a1, a1_cs, dw, dw_cs, db, db_cs, scratch, scratch_floats, K, B, KS,
-                               stream);
+                               flags, stream);
     int np, ns;
     wgrad_split(K, B, KS, num_cus(), np, ns);
     if (scratch == nullptr || scratch_floats < (long)K * ns * (KS * KS * COUT * CIN + COUT)) ns = 1;

@@ -27,6 +27,9 @@
 // fedstellar/learning/pytorch/femnist/models/cnn.py:137-139,147-148.
 #include "conv_f32.h"
 
+#include <map>
+#include <mutex>
+
 namespace {
 
 constexpr int P1 = 14, P2 = 7, CELLS1 = 196, CELLS2 = 49;
@@ -92,13 +95,17 @@ struct FwdArgs {
 // 2 samples per block: M = 98 pool windows x 4 pixels (pool-ordered: the four rows of a window are four
 // consecutive accumulator registers of one lane -> bias + ReLU + max-pool + arg-max code in registers) = 13 row
 // tiles, x 2 column halves = 26 work units dealt 7 / 7 / 6 / 6 to the four waves (wave & 1 = its column half).
-template <int KS>
-__global__ __launch_bounds__(256) void conv2_fwd_f32_kernel(FwdArgs a) {
+//
+// S = 1 is the small-footprint variant for the two-stream step (flags & CONV_CORESIDENT): 58 KB of LDS and <= 128
+// registers, so that a block fits on a CU BESIDE the two resident workgroups of the fused wgrad+Adam kernel (2 x 37 KB,
+// 2 x 192 registers per SIMD) and its MFMAs fill the matrix pipe that kernel leaves idle while it waits for HBM.
+// 7 row tiles x 2 halves = 14 units dealt 4 / 4 / 3 / 3: less even, which does not matter under the update.
+template <int KS, int S>
+__device__ __forceinline__ void conv2_fwd_f32_body(const FwdArgs& a) {
     using G = GeoF<KS>;
-    constexpr int S = 2;
-    constexpr int NWIN = S * CELLS2;           // 98
-    constexpr int NTILE = (NWIN + 7) / 8;      // 13
-    constexpr int MU = (NTILE + 1) / 2;        // row tiles per wave: 7 (even tiles) or 6 (odd tiles)
+    constexpr int NWIN = S * CELLS2;           // 98 / 49
+    constexpr int NTILE = (NWIN + 7) / 8;      // 13 / 7
+    constexpr int MU = (NTILE + 1) / 2;        // row tiles per wave: 7 (even tiles) or 6 (odd tiles) / 4 or 3
     constexpr int XN = S * CIN * G::CS;
     __shared__ __attribute__((aligned(16))) float ximg[(XN + 3) / 4 * 4];
     __shared__ __attribute__((aligned(16))) float wbuf[2][CIN * COUT];
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(256) void conv2_fwd_f32_kernel(FwdArgs a) {
 #pragma unroll
     for (int i = 0; i < MU; ++i) {
         int W = (tile0 + 2 * i) * 8 + (r >> 2);
-        if (W >= NWIN) W = 0;
+        if (W >= NWIN) W = 0;                  // also the whole surplus tile of the odd-tile waves
         const int q = r & 3, s = W / CELLS2, cell = W % CELLS2;
         const int y = 2 * (cell / P2) + (q >> 1), x = 2 * (cell % P2) + (q & 1);
         abase[i] = (s * CIN + h) * G::CS + y * G::IW + x;
@@ -167,9 +174,11 @@ __global__ __launch_bounds__(256) void conv2_fwd_f32_kernel(FwdArgs a) {
 #pragma unroll
         for (int s = 0; s < CIN / 2; ++s) {
             const float bv = wb[2 * s * COUT];
+            // (no `i < ntile` guard: a wave with one tile less recomputes a clamped tile instead - it would wait for
+            //  the others at the barrier anyway, and the guarded form compiles to a branch + accumulator copies per MFMA)
 #pragma unroll
             for (int i = 0; i < MU; ++i)
-                if (i < ntile) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[i][2 * s * G::CS], bv, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[i][2 * s * G::CS], bv, acc[i], 0, 0, 0);
         }
         if (t + 1 < G::T) {
 #pragma unroll
@@ -228,14 +237,17 @@ struct DgradArgs {
     int K, B;
 };
 
-template <int KS>
-__global__ __launch_bounds__(256) void conv2_dgrad_f32_kernel(DgradArgs a) {
+// CH = channels of the gradient image resident at a time: 64 (one pass, 100 KB of LDS) or 32 (two passes over the
+// taps, 50 KB and <= 128 registers: the variant that fits beside the fused update kernel, see the forward kernel).
+template <int KS, int CH>
+__device__ __forceinline__ void conv2_dgrad_f32_body(const DgradArgs& a) {
     using G = GeoF<KS>;
     constexpr int NTILE = (CELLS1 + 31) / 32;   // 7
     constexpr int MT = (NTILE + 3) / 4;         // (2,2,2,1)
-    constexpr int GN = COUT * G::CS;
+    constexpr int GN = CH * G::CS;
+    constexpr int WU = CH * CIN / 4 / 256;      // float4 of a weight slice per thread: 2 / 1
     __shared__ __attribute__((aligned(16))) float gimg[(GN + 3) / 4 * 4];
-    __shared__ __attribute__((aligned(16))) float wbuf[2][COUT * CIN];
+    __shared__ __attribute__((aligned(16))) float wbuf[2][CH * CIN];
 
     int c, b;
     if (!xcd_map(a.B, a.K, c, b)) return;
@@ -243,29 +255,6 @@ __global__ __launch_bounds__(256) void conv2_dgrad_f32_kernel(DgradArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
 
-    for (int i = tid; i < (GN + 3) / 4; i += 256)
-        reinterpret_cast<f32x4*>(gimg)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* wd = a.wp + c * a.wp_cs + G::T * COUT * CIN;
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-        reinterpret_cast<f32x4*>(wbuf[0])[tid + 256 * u] = reinterpret_cast<const f32x4*>(wd)[tid + 256 * u];
-    __syncthreads();
-    {
-        const float* gsrc = a.g + c * a.g_cs + (size_t)b * COUT * CELLS2;
-        const uint8_t* csrc = a.code + c * a.c_cs + (size_t)b * COUT * CELLS2;
-        for (int task = tid; task < COUT * CELLS2; task += 256) {
-            const int co = task / CELLS2, cell = task - co * CELLS2;
-            const float gv = gsrc[task];
-            const int q = csrc[task];
-            if (q < 4) {
-                const int Y = 2 * (cell / P2) + G::PAD + (q >> 1), X = 2 * (cell % P2) + G::PAD + (q & 1);
-                gimg[co * G::CS + Y * G::IW + X] = gv;
-            }
-        }
-    }
-    __syncthreads();
-
-    const int ntile = (NTILE - wave + 3) / 4;
     int abase[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -278,34 +267,62 @@ __global__ __launch_bounds__(256) void conv2_dgrad_f32_kernel(DgradArgs a) {
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    const int ntile = (NTILE - wave + 3) / 4;
 
-    int ky = 0, kx = 0;   // mirrored tap index: image offset (ky,kx), weights of tap (KS-1-ky, KS-1-kx)
 #pragma unroll 1
-    for (int t = 0; t < G::T; ++t) {
-        f32x4 wnext[2];
-        if (t + 1 < G::T) {
+    for (int pass = 0; pass < COUT / CH; ++pass) {
+        // mirrored-tap weights [t'][co][ci]: rows co of this pass are one contiguous piece of a tap slice
+        const float* wd = a.wp + c * a.wp_cs + G::T * COUT * CIN + pass * CH * CIN;
+        if (pass > 0) __syncthreads();        // everyone is done with the previous image
+        for (int i = tid; i < (GN + 3) / 4; i += 256)
+            reinterpret_cast<f32x4*>(gimg)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-                wnext[u] = reinterpret_cast<const f32x4*>(wd + (t + 1) * COUT * CIN)[tid + 256 * u];
-        }
-        const float* wb = wbuf[t & 1] + h * CIN + r;
-        const int toff = ky * G::IW + kx;
-        const float* ap[MT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) ap[i] = gimg + abase[i] + toff;
-#pragma unroll
-        for (int s = 0; s < COUT / 2; ++s) {
-            const float bv = wb[2 * s * CIN];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-                if (i < ntile) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[i][2 * s * G::CS], bv, acc[i], 0, 0, 0);
-        }
-        if (t + 1 < G::T) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) reinterpret_cast<f32x4*>(wbuf[(t + 1) & 1])[tid + 256 * u] = wnext[u];
+        for (int u = 0; u < WU; ++u)
+            reinterpret_cast<f32x4*>(wbuf[0])[tid + 256 * u] = reinterpret_cast<const f32x4*>(wd)[tid + 256 * u];
+        __syncthreads();
+        {
+            const float* gsrc = a.g + c * a.g_cs + ((size_t)b * COUT + pass * CH) * CELLS2;
+            const uint8_t* csrc = a.code + c * a.c_cs + ((size_t)b * COUT + pass * CH) * CELLS2;
+            for (int task = tid; task < CH * CELLS2; task += 256) {
+                const int co = task / CELLS2, cell = task - co * CELLS2;
+                const float gv = gsrc[task];
+                const int q = csrc[task];
+                if (q < 4) {
+                    const int Y = 2 * (cell / P2) + G::PAD + (q >> 1), X = 2 * (cell % P2) + G::PAD + (q & 1);
+                    gimg[co * G::CS + Y * G::IW + X] = gv;
+                }
+            }
         }
         __syncthreads();
-        if (++kx == KS) { kx = 0; ++ky; }
+
+        int ky = 0, kx = 0;   // mirrored tap index: image offset (ky,kx), weights of tap (KS-1-ky, KS-1-kx)
+#pragma unroll 1
+        for (int t = 0; t < G::T; ++t) {
+            f32x4 wnext[WU];
+            if (t + 1 < G::T) {
+#pragma unroll
+                for (int u = 0; u < WU; ++u)
+                    wnext[u] = reinterpret_cast<const f32x4*>(wd + (t + 1) * COUT * CIN)[tid + 256 * u];
+            }
+            const float* wb = wbuf[t & 1] + h * CIN + r;
+            const int toff = ky * G::IW + kx;
+            const float* ap[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) ap[i] = gimg + abase[i] + toff;
+#pragma unroll
+            for (int s = 0; s < CH / 2; ++s) {
+                const float bv = wb[2 * s * CIN];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)      // (unguarded on purpose, see the forward kernel)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[i][2 * s * G::CS], bv, acc[i], 0, 0, 0);
+            }
+            if (t + 1 < G::T) {
+#pragma unroll
+                for (int u = 0; u < WU; ++u) reinterpret_cast<f32x4*>(wbuf[(t + 1) & 1])[tid + 256 * u] = wnext[u];
+            }
+            __syncthreads();
+            if (++kx == KS) { kx = 0; ++ky; }
+        }
     }
 
     // ---- epilogue: lane = input channel, registers 4g..4g+3 = four consecutive pixels -> float4
@@ -331,8 +348,8 @@ __global__ __launch_bounds__(256) void conv2_dgrad_f32_kernel(DgradArgs a) {
 // fragment read is a conflict-free ds_read_b32 (the bf16 kernel needs transposing reads here). A block owns
 // (client, 1/NP of the taps, 1/NS of the batch) and walks its samples, so its accumulators are final sums: plain
 // stores (or per-split partials summed by conv2_wgrad_reduce_f32_kernel), no atomics, bitwise reproducible.
-// 8 waves = 4 tap groups x 2 row tiles; a wave shares its G value across its taps; the bias gradient rides along
-// as one more MFMA against ones. The next sample's rows are fetched into registers while this one is multiplied.
+// 8 waves = 4 tap groups x 2 row tiles; a wave shares its G value across its taps; the bias gradient is a running
+// VALU sum of the same G values. The next sample's rows are fetched into registers while this one is multiplied.
 // ---------------------------------------------------------------------------------------
 struct WgradArgs {
     const float* g;    long g_cs;      // da2 [K][B][64][49]
@@ -344,38 +361,45 @@ struct WgradArgs {
     float* part;       int NS;         // NS > 1: batch split, partials [K][NS][T*64*32 + 64]
 };
 
-template <int KS, int NP>
-__global__ __launch_bounds__(512) void conv2_wgrad_f32_kernel(WgradArgs a) {
+// MH = output channels per block: 64 (8 waves = 4 tap groups x 2 row tiles, 92 KB of LDS) or 32 (4 waves = 4 tap
+// groups of ONE row tile, blockIdx -> (.., row tile), 67 KB, <= 128 registers with NP >= 2: the variant that fits
+// beside the fused update kernel, see the forward kernel).
+template <int KS, int NP, int MH>
+__device__ __forceinline__ void conv2_wgrad_f32_body(const WgradArgs& a) {
     using G = GeoF<KS>;
     constexpr int T = G::T;
+    constexpr int NTH = MH * 8;                          // threads: 512 / 256
     constexpr int NTAP = ((T + NP - 1) / NP + 3) / 4;    // most taps per wave
     constexpr int GCS = CELLS1 + 1;                      // 197: odd channel stride of the routed gradient
-    constexpr int XN = CIN * G::CS, GN = COUT * GCS;
+    constexpr int XN = CIN * G::CS, GN = MH * GCS;
     constexpr int NX4 = CIN * CELLS1 / 4;                // float4 of the activations of a sample: 1568
-    constexpr int XU = (NX4 + 511) / 512;                // per thread: 4
-    constexpr int NG = COUT * CELLS2;                    // pooled gradient values of a sample: 3136
-    constexpr int GU = (NG + 511) / 512;                 // per thread: 7
+    constexpr int XU = (NX4 + NTH - 1) / NTH;            // per thread: 4 / 7
+    constexpr int NG = MH * CELLS2;                      // pooled gradient values of a sample (and block): 3136 / 1568
+    constexpr int GU = (NG + NTH - 1) / NTH;             // per thread: 7
     __shared__ __attribute__((aligned(16))) float ximg[(XN + 3) / 4 * 4];
     __shared__ __attribute__((aligned(16))) float gimg[(GN + 3) / 4 * 4];
 
+    constexpr int NMT = COUT / MH;                       // row-tile blocks per (client, tap part, split): 1 / 2
     int c, sub;
-    if (!xcd_map(NP * a.NS, a.K, c, sub)) return;
-    const int tp = sub % NP, split = sub / NP;
+    if (!xcd_map(NP * a.NS * NMT, a.K, c, sub)) return;
+    const int mblk = sub % NMT, tp = (sub / NMT) % NP, split = sub / (NMT * NP);
     const int b_begin = split * a.B / a.NS, b_end = (split + 1) * a.B / a.NS;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int tg = wave >> 1, mt = wave & 1;
+    const int tg = MH == 64 ? wave >> 1 : wave;          // tap group
+    const int mloc = MH == 64 ? wave & 1 : 0;            // row tile inside the block's gradient image
+    const int mt = MH == 64 ? mloc : mblk;               // row tile of the product
     // taps of this block [p0, p0 + np) split over the four tap groups; (part 0, group 0) also owns the bias
     const int p0 = tp * T / NP, np = (tp + 1) * T / NP - p0;
     const int t_begin = p0 + tg * np / 4;
     const int ntap = p0 + (tg + 1) * np / 4 - t_begin;
     const bool do_bias = (tp == 0 && tg == 0);     // wave-uniform
 
-    for (int i = tid; i < (XN + 3) / 4; i += 512)
+    for (int i = tid; i < (XN + 3) / 4; i += NTH)
         reinterpret_cast<f32x4*>(ximg)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int i = tid; i < (GN + 3) / 4; i += 512)
+    for (int i = tid; i < (GN + 3) / 4; i += NTH)
         reinterpret_cast<f32x4*>(gimg)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const float* xp[NTAP];
@@ -384,7 +408,7 @@ __global__ __launch_bounds__(512) void conv2_wgrad_f32_kernel(WgradArgs a) {
         const int t = min(t_begin + j, T - 1);
         xp[j] = ximg + r * G::CS + h + (t / KS) * G::IW + (t % KS);
     }
-    const float* gp = gimg + (mt * 32 + r) * GCS + h;
+    const float* gp = gimg + (mloc * 32 + r) * GCS + h;
 
     // staging roles (global -> registers -> LDS)
     f32x4 xv[XU]; float gv[GU]; uint8_t qc[GU];
@@ -392,17 +416,17 @@ __global__ __launch_bounds__(512) void conv2_wgrad_f32_kernel(WgradArgs a) {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.a1 + c * a.a1_cs + (size_t)b * CIN * CELLS1);
 #pragma unroll
         for (int u = 0; u < XU; ++u)
-            if (tid + 512 * u < NX4) xv[u] = src[tid + 512 * u];
-        const float* gs = a.g + c * a.g_cs + (size_t)b * NG;
-        const uint8_t* cs = a.code + c * a.c_cs + (size_t)b * NG;
+            if (tid + NTH * u < NX4) xv[u] = src[tid + NTH * u];
+        const float* gs = a.g + c * a.g_cs + ((size_t)b * COUT + (MH == 64 ? 0 : mblk * 32)) * CELLS2;
+        const uint8_t* cs = a.code + c * a.c_cs + ((size_t)b * COUT + (MH == 64 ? 0 : mblk * 32)) * CELLS2;
 #pragma unroll
         for (int u = 0; u < GU; ++u)
-            if (tid + 512 * u < NG) { gv[u] = gs[tid + 512 * u]; qc[u] = cs[tid + 512 * u]; }
+            if (tid + NTH * u < NG) { gv[u] = gs[tid + NTH * u]; qc[u] = cs[tid + NTH * u]; }
     };
     auto commit = [&]() {
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
-            const int i = tid + 512 * u;
+            const int i = tid + NTH * u;
             if (i < NX4) {
                 const int ch = i / (CELLS1 / 4), j = i - ch * (CELLS1 / 4);
                 float* dst = ximg + ch * G::CS + G::PAD * G::IW + G::PAD;
@@ -415,7 +439,7 @@ __global__ __launch_bounds__(512) void conv2_wgrad_f32_kernel(WgradArgs a) {
         }
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
-            const int i = tid + 512 * u;
+            const int i = tid + NTH * u;
             if (i < NG) {
                 const int co = i / CELLS2, cell = i - co * CELLS2;
                 float* dst = gimg + co * GCS + 2 * (cell / P2) * P1 + 2 * (cell % P2);
@@ -428,36 +452,67 @@ __global__ __launch_bounds__(512) void conv2_wgrad_f32_kernel(WgradArgs a) {
         }
     };
 
-    f32x16 acc[NTAP], accb;
+    f32x16 acc[NTAP];
 #pragma unroll
     for (int j = 0; j < NTAP; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) accb[e] = 0.f;
+    float bsum = 0.f;           // bias gradient of channel mt*32 + r over this lane half's pixels (plain VALU adds)
 
-    if (b_begin < b_end) prefetch(b_begin);
+    // MH == 64: the next sample's rows are fetched into registers while this one is multiplied. The small variant
+    // has no registers for that (128 in all, 64 of them accumulators): it stages each sample in place, and the
+    // exposed fetch latency is covered by the other workgroups of the CU (it runs under the fused update).
+    constexpr bool PREFETCH = MH == 64;
+    if (PREFETCH && b_begin < b_end) prefetch(b_begin);
     for (int item = b_begin; item < b_end; ++item) {
         __syncthreads();            // everyone finished reading the previous images (or zero-filling)
-        commit();
-        __syncthreads();
-        if (item + 1 < b_end) prefetch(item + 1);
-
+        if constexpr (PREFETCH) {
+            commit();
+        } else {        // rolled loops, a few loads in flight each: no register arrays, no hoisted address tables
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.a1 + c * a.a1_cs + (size_t)item * CIN * CELLS1);
 #pragma unroll 2
+            for (int i = tid; i < NX4; i += NTH) {
+                const f32x4 v = src[i];
+                const int ch = i / (CELLS1 / 4), j = i - ch * (CELLS1 / 4);
+                float* dst = ximg + ch * G::CS + G::PAD * G::IW + G::PAD;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int p = 4 * j + e, y = p / P1, x = p - y * P1;
+                    dst[y * G::IW + x] = v[e];
+                }
+            }
+            const float* gs = a.g + c * a.g_cs + ((size_t)item * COUT + mblk * 32) * CELLS2;
+            const uint8_t* cs = a.code + c * a.c_cs + ((size_t)item * COUT + mblk * 32) * CELLS2;
+#pragma unroll 4
+            for (int i = tid; i < NG; i += NTH) {
+                const float g = gs[i];
+                const int q = cs[i];
+                const int co = i / CELLS2, cell = i - co * CELLS2;
+                float* dst = gimg + co * GCS + 2 * (cell / P2) * P1 + 2 * (cell % P2);
+                dst[0] = q == 0 ? g : 0.f;
+                dst[1] = q == 1 ? g : 0.f;
+                dst[P1] = q == 2 ? g : 0.f;
+                dst[P1 + 1] = q == 3 ? g : 0.f;
+            }
+        }
+        __syncthreads();
+        if (PREFETCH && item + 1 < b_end) prefetch(item + 1);
+
+#pragma unroll 1
         for (int y = 0; y < P1; ++y) {
 #pragma unroll
             for (int xs = 0; xs < P1 / 2; ++xs) {
                 const float av = gp[y * P1 + 2 * xs];
+                bsum += av;
 #pragma unroll
-                for (int j = 0; j < NTAP; ++j)
-                    if (j < ntap)
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xp[j][y * G::IW + 2 * xs], acc[j], 0, 0, 0);
-                if (do_bias) accb = __builtin_amdgcn_mfma_f32_32x32x2f32(av, 1.0f, accb, 0, 0, 0);
+                for (int j = 0; j < NTAP; ++j)    // (unguarded: a group with one tap less recomputes its last tap)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xp[j][y * G::IW + 2 * xs], acc[j], 0, 0, 0);
             }
         }
     }
 
     const int ci = r;
+    bsum += __shfl_xor(bsum, 32, 64);      // both pixel parities
     if (a.NS > 1) {
         // partial of this batch split, tap-major [t][n][ci], then the bias
         float* pw = a.part + ((size_t)c * a.NS + split) * (T * COUT * CIN + COUT);
@@ -469,10 +524,7 @@ __global__ __launch_bounds__(512) void conv2_wgrad_f32_kernel(WgradArgs a) {
                     pw[((t_begin + j) * COUT + mt * 32 + mfma_row_(e, lane)) * CIN + ci] = acc[j][e];
             }
         }
-        if (do_bias && ci == 0) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) pw[T * COUT * CIN + mt * 32 + mfma_row_(e, lane)] = accb[e];
-        }
+        if (do_bias && h == 0) pw[T * COUT * CIN + mt * 32 + r] = bsum;
         return;
     }
     float* dw = a.dw + c * a.dw_cs;
@@ -486,12 +538,26 @@ __global__ __launch_bounds__(512) void conv2_wgrad_f32_kernel(WgradArgs a) {
             }
         }
     }
-    if (do_bias && ci == 0) {
-        float* db = a.db + c * a.db_cs;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) db[mt * 32 + mfma_row_(e, lane)] = accb[e];
-    }
+    if (do_bias && h == 0) a.db[c * a.db_cs + mt * 32 + r] = bsum;
 }
+
+// Kernel entry points. The *_small variants are capped at 128 registers (VGPR + AGPR): with the 2 x 192 of the two
+// resident fused-update workgroups that is exactly one SIMD's file, i.e. a block of theirs fits beside them.
+template <int KS>
+__global__ __launch_bounds__(256) void conv2_fwd_f32_kernel(FwdArgs a) { conv2_fwd_f32_body<KS, 2>(a); }
+template <int KS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(128)))
+void conv2_fwd_f32_small_kernel(FwdArgs a) { conv2_fwd_f32_body<KS, 1>(a); }
+template <int KS>
+__global__ __launch_bounds__(256) void conv2_dgrad_f32_kernel(DgradArgs a) { conv2_dgrad_f32_body<KS, 64>(a); }
+template <int KS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(128)))
+void conv2_dgrad_f32_small_kernel(DgradArgs a) { conv2_dgrad_f32_body<KS, 32>(a); }
+template <int KS, int NP>
+__global__ __launch_bounds__(512) void conv2_wgrad_f32_kernel(WgradArgs a) { conv2_wgrad_f32_body<KS, NP, 64>(a); }
+template <int KS, int NP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(128)))
+void conv2_wgrad_f32_small_kernel(WgradArgs a) { conv2_wgrad_f32_body<KS, NP, 32>(a); }
 
 // Sum of the NS batch-split partials [t][n][ci] -> dW[n][ci][t], db[n]. One block per (client, n).
 template <int KS>
@@ -516,6 +582,28 @@ __global__ __launch_bounds__(256) void conv2_wgrad_reduce_f32_kernel(WgradArgs a
     for (int i = threadIdx.x; i < CIN * T; i += 256) dw[i] = tr[i];
 }
 
+// Dynamic LDS that pads a small-variant block to 86 KB. Two fused-update workgroups (2 x 36 KB) + ONE such block fill
+// the 160 KB of a CU exactly; without the padding the dispatcher packs TWO of the (higher-priority) convolution blocks
+// onto a CU, only one update workgroup still fits beside them and the HBM-bound update runs at 40 % of its rate
+// (measured: 3.0 -> 4.9 ms per step for 100 clients).
+size_t coresident_pad(const void* kernel) {
+    static std::mutex mu;
+    static std::map<const void*, size_t> pads;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = pads.find(kernel);
+    if (it != pads.end()) return it->second;
+    hipFuncAttributes attr;
+    size_t pad = 0;
+    const char* e = getenv("P2PFL_CORES_LDS_KB");
+    const size_t TARGET = (e ? (size_t)atoi(e) : 64) * 1024;
+    if (hipFuncGetAttributes(&attr, kernel) == hipSuccess && attr.sharedSizeBytes < TARGET)
+        pad = TARGET - attr.sharedSizeBytes;
+    pads[kernel] = pad;
+    return pad;
+}
+#define LAUNCH_SMALL(kernel, grid, block, stream, args) \
+    hipLaunchKernelGGL(kernel, grid, block, coresident_pad(reinterpret_cast<const void*>(&kernel)), stream, args)
+
 int num_cus() {
     static int n = 0;
     if (n <= 0) {
@@ -532,18 +620,21 @@ int num_cus() {
 // blocks over the CUs, samples over the batch splits, taps over the four tap groups of a block. Tap parts
 // multiply the staging work and batch splits the partial-sum traffic (small penalties).
 //   5x5: 100 clients -> 1 x 5 (500 blocks = 1.95 waves), 10 -> 5 x 5;  3x3: 1000 -> 1 x 1, 50 -> 1 x 5
-void wgrad_split_f32(int K, int B, int KS, int cus, int& np, int& ns) {
-    static const int parts[3] = {1, 2, 5};
+// small (co-resident variant): one row tile per block (twice the blocks), np >= 2 (register budget)
+void wgrad_split_f32(int K, int B, int KS, int cus, bool small, int& np, int& ns) {
+    // small: <= 4 accumulators per wave (128-register budget): >= 2 tap parts
+    static const int parts_big[3] = {1, 2, 5}, parts_small5[3] = {2, 3, 5}, parts_small3[3] = {2, 3, 5};
+    const int* parts = !small ? parts_big : (KS == 5 ? parts_small5 : parts_small3);
     const int T = KS * KS;
     double best = -1.0;
-    np = 1; ns = 1;
+    np = parts[0]; ns = 1;
     for (int i = 0; i < 3; ++i) {
         const int p = parts[i];
         if (p > T) continue;
         const int ntap = ((T + p - 1) / p + 3) / 4;
         const double tapbal = (double)T / (p * 4 * ntap);
         for (int s = 1; s <= 8 && s <= B; ++s) {
-            const long blocks = (long)K * p * s;
+            const long blocks = (long)K * p * s * (small ? 2 : 1);
             const double fill = (double)blocks / ((double)((blocks + cus - 1) / cus) * cus);
             const double bbal = (double)B / (s * ((B + s - 1) / s));
             const double e = tapbal * fill * bbal / (1.0 + 0.05 * (p - 1)) / (1.0 + 0.01 * (s - 1));
@@ -553,12 +644,19 @@ void wgrad_split_f32(int K, int B, int KS, int cus, int& np, int& ns) {
 }
 
 template <int KS>
-void launch_wgrad(const WgradArgs& a, int np, hipStream_t stream) {
-    const dim3 block(512);
+void launch_wgrad(const WgradArgs& a, int np, bool small, hipStream_t stream) {
     const int slots = cdiv(a.K, 8) * 8 * a.NS;
-    if (np == 1) hipLaunchKernelGGL((conv2_wgrad_f32_kernel<KS, 1>), dim3(slots), block, 0, stream, a);
-    else if (np == 2) hipLaunchKernelGGL((conv2_wgrad_f32_kernel<KS, 2>), dim3(slots * 2), block, 0, stream, a);
-    else hipLaunchKernelGGL((conv2_wgrad_f32_kernel<KS, 5>), dim3(slots * 5), block, 0, stream, a);
+    if (small) {
+        const dim3 block(256);
+        if (np == 2) LAUNCH_SMALL((conv2_wgrad_f32_small_kernel<KS, 2>), dim3(slots * 4), block, stream, a);
+        else if (np == 3) LAUNCH_SMALL((conv2_wgrad_f32_small_kernel<KS, 3>), dim3(slots * 6), block, stream, a);
+        else LAUNCH_SMALL((conv2_wgrad_f32_small_kernel<KS, 5>), dim3(slots * 10), block, stream, a);
+    } else {
+        const dim3 block(512);
+        if (np == 1) hipLaunchKernelGGL((conv2_wgrad_f32_kernel<KS, 1>), dim3(slots), block, 0, stream, a);
+        else if (np == 2) hipLaunchKernelGGL((conv2_wgrad_f32_kernel<KS, 2>), dim3(slots * 2), block, 0, stream, a);
+        else hipLaunchKernelGGL((conv2_wgrad_f32_kernel<KS, 5>), dim3(slots * 5), block, 0, stream, a);
+    }
     if (a.NS > 1)
         hipLaunchKernelGGL(conv2_wgrad_reduce_f32_kernel<KS>, dim3(COUT, a.K), dim3(256), 0, stream, a);
 }
@@ -576,11 +674,18 @@ int conv2_prep_f32(const float* w, long w_cs, float* wp, long wp_cs, int K, int 
 }
 
 int conv2_fwd_f32(const float* a1, long a1_cs, const float* wp, long wp_cs, const float* bias, long b_cs, float* a2,
-                  long a2_cs, uint8_t* code, long c_cs, int K, int B, int KS, hipStream_t stream) {
+                  long a2_cs, uint8_t* code, long c_cs, int K, int B, int KS, int flags, hipStream_t stream) {
     if (K <= 0 || B <= 0) return -1;
     if ((wp_cs & 3) || ((uintptr_t)wp & 15) || ((uintptr_t)a1 & 15) || (a1_cs & 3)) return -2;
     if (((uintptr_t)a2 & 15) || (a2_cs & 3) || ((uintptr_t)code & 15) || (c_cs & 15)) return -2;   // 16-byte block stores
     FwdArgs a{a1, a1_cs, wp, wp_cs, bias, b_cs, a2, a2_cs, code, c_cs, K, B};
+    if (flags & CONV_CORESIDENT) {
+        dim3 grid(cdiv(K, 8) * 8 * B);
+        if (KS == 5) LAUNCH_SMALL(conv2_fwd_f32_small_kernel<5>, grid, dim3(256), stream, a);
+        else if (KS == 3) LAUNCH_SMALL(conv2_fwd_f32_small_kernel<3>, grid, dim3(256), stream, a);
+        else return -3;
+        P2PFL_RETURN_LAST_ERROR();
+    }
     dim3 grid(cdiv(K, 8) * 8 * cdiv(B, 2));
     if (KS == 5) hipLaunchKernelGGL(conv2_fwd_f32_kernel<5>, grid, dim3(256), 0, stream, a);
     else if (KS == 3) hipLaunchKernelGGL(conv2_fwd_f32_kernel<3>, grid, dim3(256), 0, stream, a);
@@ -589,35 +694,41 @@ int conv2_fwd_f32(const float* a1, long a1_cs, const float* wp, long wp_cs, cons
 }
 
 int conv2_dgrad_f32(const float* g, long g_cs, const uint8_t* code, long c_cs, const float* wp, long wp_cs,
-                    float* da1, long da1_cs, int K, int B, int KS, hipStream_t stream) {
+                    float* da1, long da1_cs, int K, int B, int KS, int flags, hipStream_t stream) {
     if (K <= 0 || B <= 0) return -1;
     if ((wp_cs & 3) || ((uintptr_t)wp & 15) || (da1_cs & 3) || ((uintptr_t)da1 & 15)) return -2;
     DgradArgs a{g, g_cs, code, c_cs, wp, wp_cs, da1, da1_cs, K, B};
     dim3 grid(cdiv(K, 8) * 8 * B);
-    if (KS == 5) hipLaunchKernelGGL(conv2_dgrad_f32_kernel<5>, grid, dim3(256), 0, stream, a);
+    const bool small = flags & CONV_CORESIDENT;
+    if (KS == 5 && small) LAUNCH_SMALL(conv2_dgrad_f32_small_kernel<5>, grid, dim3(256), stream, a);
+    else if (KS == 5) hipLaunchKernelGGL(conv2_dgrad_f32_kernel<5>, grid, dim3(256), 0, stream, a);
+    else if (KS == 3 && small) LAUNCH_SMALL(conv2_dgrad_f32_small_kernel<3>, grid, dim3(256), stream, a);
     else if (KS == 3) hipLaunchKernelGGL(conv2_dgrad_f32_kernel<3>, grid, dim3(256), 0, stream, a);
     else return -3;
     P2PFL_RETURN_LAST_ERROR();
 }
 
-long conv2_wgrad_f32_scratch(int K, int B, int KS) {
+long conv2_wgrad_f32_scratch(int K, int B, int KS) {      // (enough for either variant)
     if (K <= 0 || B <= 0) return 0;
-    int np, ns;
-    wgrad_split_f32(K, B, KS, num_cus(), np, ns);
+    int np, ns, ns2;
+    wgrad_split_f32(K, B, KS, num_cus(), false, np, ns);
+    wgrad_split_f32(K, B, KS, num_cus(), true, np, ns2);
+    ns = ns > ns2 ? ns : ns2;
     return ns > 1 ? (long)K * ns * (KS * KS * COUT * CIN + COUT) : 0;
 }
 
 int conv2_wgrad_f32(const float* g, long g_cs, const uint8_t* code, long c_cs, const float* a1, long a1_cs, float* dw,
                     long dw_cs, float* db, long db_cs, float* scratch, long scratch_floats, int K, int B, int KS,
-                    hipStream_t stream) {
+                    int flags, hipStream_t stream) {
     if (K <= 0 || B <= 0) return -1;
     if (((uintptr_t)a1 & 15) || (a1_cs & 3)) return -2;
+    const bool small = flags & CONV_CORESIDENT;
     int np, ns;
-    wgrad_split_f32(K, B, KS, num_cus(), np, ns);
+    wgrad_split_f32(K, B, KS, num_cus(), small, np, ns);
     if (scratch == nullptr || scratch_floats < (long)K * ns * (KS * KS * COUT * CIN + COUT)) ns = 1;
     WgradArgs a{g, g_cs, code, c_cs, a1, a1_cs, dw, dw_cs, db, db_cs, K, B, scratch, ns};
-    if (KS == 5) launch_wgrad<5>(a, np, stream);
-    else if (KS == 3) launch_wgrad<3>(a, np, stream);
+    if (KS == 5) launch_wgrad<5>(a, np, small, stream);
+    else if (KS == 3) launch_wgrad<3>(a, np, small, stream);
     else return -3;
     P2PFL_RETURN_LAST_ERROR();
 }

@@ -328,6 +328,7 @@ struct WgradAdamArgs {
     int B, In, Out;
     AdamHyper h;
     const int* sidx; long s_cs;
+    int hiprio;
 };
 
 // WR x WC waves: block tile (32 WR) x (128 WC). Wider tiles (WC = 4: 32 x 512) turn the weight/moment
@@ -361,6 +362,10 @@ constexpr int UPDATE_KERNEL_RESERVE = 12;      // -> 188 VGPRs: two waves per SI
 template <int WR, int WC, bool FRESH, int RESERVE, class T>
 __global__ __launch_bounds__(256, 2)
 void linear_wgrad_adam_kernel(WgradAdamArgs a) {
+    // The few instructions of this HBM-bound kernel go first: beside matrix-pipe-bound convolution waves (fp32 two-stream
+    // step) its 64 MFMAs per wave otherwise queue behind theirs, every workgroup lives longer and the weight /
+    // moment stream - the critical path of the step - thins out (measured: 3.0 -> 4.8 ms per step).
+    if (a.hiprio) __builtin_amdgcn_s_setprio(3);
     RegisterReserve<RESERVE> reserve;
     constexpr int BM = 32 * WR, BN = 128 * WC;
     __shared__ GemmSmem<BM, BN, 1, GEMM_BK, T> sm;
@@ -466,7 +471,11 @@ P2PFL_API int p2pfl_linear_wgrad_adam(const float* dy, long dy_cs, const float* 
     const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
     WgradAdamArgs a{dy, dy_cs, x, x_cs, w, mw, vw, w_cs, b, mb, vb, b_cs, B, In, Out,
                     AdamHyper{lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
-                              (float)(1.0 / sqrt(bc2)), bc, fresh}, sidx, s_cs};
+                              (float)(1.0 / sqrt(bc2)), bc, fresh}, sidx, s_cs, 0};
+    {
+        const char* e = getenv("P2PFL_UPDATE_PRIO");
+        a.hiprio = e ? atoi(e) != 0 : 1;
+    }
     // 128 x 128 tiles, 2 workgroups per CU: measured best of {128x128, 64x256, 32x512} x {2, 3, 4 per CU}
     // (2.87 / 2.90 / 3.31 ms and 2.87 / 2.99 / 4.09 ms for 100 clients x 3136x2048 on MI355X)
     const dim3 grid(cdiv(In + 1, 128), cdiv(Out, 128), K);

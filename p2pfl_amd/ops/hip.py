@@ -116,10 +116,10 @@ class _Sig:
     p2pfl_conv1_fwd = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, P]
     p2pfl_conv1_wgrad = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, P]
     p2pfl_conv2_prep = [P, L, P, L, I, I, I, I, I, P]
-    p2pfl_conv2_fwd = [P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, I, P]
-    p2pfl_conv2_wgrad = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, I, P]
+    p2pfl_conv2_fwd = [P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, I, I, P]
+    p2pfl_conv2_wgrad = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, I, I, P]
     p2pfl_conv2_wgrad_scratch = [I, I, I, I]
-    p2pfl_conv2_dgrad = [P, L, P, L, P, L, P, L, I, I, I, I, I, I, P]
+    p2pfl_conv2_dgrad = [P, L, P, L, P, L, P, L, I, I, I, I, I, I, I, P]
     p2pfl_softmax_ce = [P, L, P, L, P, L, P, L, P, P, P, P, P, L, I, I, I, P]
     p2pfl_zero_rows = [P, L, I, I, P]
     p2pfl_adam_step = [P, P, P, P, L, L, I, F, F, F, F, F, I, P, P]
@@ -293,8 +293,10 @@ def conv2_prep(w, wprep, ks: int, prec=None) -> None:
     _chk(load().p2pfl_conv2_prep(wp, ws, pp, ps, K, Cin, Cout, ks, _prec(prec), _stream()), "conv2_prep")
 
 
-def conv2_fwd(a1, w, bias, a2, code, ks: int, wprep=None, prec=None) -> None:
+def conv2_fwd(a1, w, bias, a2, code, ks: int, wprep=None, prec=None, coresident: bool = False) -> None:
     """Stage-2 conv(Cin->Cout, ks x ks, same) + ReLU + 2x2 maxpool on the matrix cores.
+    ``coresident`` (fp32 only): the small-footprint kernel variant that fits on a CU beside the fused wgrad+Adam
+    kernel - what the two-stream training step launches on its side stream.
 
     a1 [K,B,Cin,196], w [K,Cout,Cin*ks*ks], bias [K,Cout], a2 [K,B,Cout,49], code uint8 like a2.
     ``wprep``: workspace already filled by :func:`conv2_prep` for these weights (else made here).
@@ -307,7 +309,7 @@ def conv2_fwd(a1, w, bias, a2, code, ks: int, wprep=None, prec=None) -> None:
     (ap, as_), (pp, ps), (bp, bs), (op, os_) = _pc(a1), _pc(wprep, _prep_dtype(prec)), _pc(bias), _pc(a2)
     cp, cs = _pc(code, torch.uint8)
     _chk(load().p2pfl_conv2_fwd(ap, as_, pp, ps, bp, bs, op, os_, cp, cs, K, B, Cin, Cout, ks, _prec(prec),
-                                _stream()), "conv2_fwd")
+                                int(coresident), _stream()), "conv2_fwd")
 
 
 _wgrad_scratch = {}
@@ -320,7 +322,8 @@ def conv2_wgrad_scratch(K: int, B: int, ks: int, device, prec=None) -> Optional[
     return torch.empty(need, dtype=torch.float32, device=device) if need else None
 
 
-def conv2_wgrad(g, code, a1, dw, db, ks: int, scratch: Optional[torch.Tensor] = None, prec=None) -> None:
+def conv2_wgrad(g, code, a1, dw, db, ks: int, scratch: Optional[torch.Tensor] = None, prec=None,
+                coresident: bool = False) -> None:
     """Stage-2 weight/bias gradient: dw [K,Cout,Cin*ks*ks], db [K,Cout] (overwritten).
 
     ``scratch``: buffer from :func:`conv2_wgrad_scratch` owned by the caller (one call in flight per buffer);
@@ -343,10 +346,10 @@ def conv2_wgrad(g, code, a1, dw, db, ks: int, scratch: Optional[torch.Tensor] = 
                 buf = _wgrad_scratch[key] = torch.empty(need, dtype=torch.float32, device=g.device)
         sp = buf.data_ptr()
     _chk(lib.p2pfl_conv2_wgrad(gp, gs, cp, cs, ap, as_, wp, ws, bp, bs, sp, need, K, B, Cin, Cout, ks, _prec(prec),
-                               stream), "conv2_wgrad")
+                               int(coresident), stream), "conv2_wgrad")
 
 
-def conv2_dgrad(g, code, w, da1, ks: int, wprep=None, prec=None) -> None:
+def conv2_dgrad(g, code, w, da1, ks: int, wprep=None, prec=None, coresident: bool = False) -> None:
     K, B, Cout = g.shape[0], g.shape[1], g.shape[2]
     Cin = da1.shape[2]
     if wprep is None:
@@ -354,8 +357,8 @@ def conv2_dgrad(g, code, w, da1, ks: int, wprep=None, prec=None) -> None:
         conv2_prep(w, wprep, ks, prec)
     (gp, gs), (pp, ps), (dp, ds) = _pc(g), _pc(wprep, _prep_dtype(prec)), _pc(da1)
     cp, cs = _pc(code, torch.uint8)
-    _chk(load().p2pfl_conv2_dgrad(gp, gs, cp, cs, pp, ps, dp, ds, K, B, Cin, Cout, ks, _prec(prec), _stream()),
-         "conv2_dgrad")
+    _chk(load().p2pfl_conv2_dgrad(gp, gs, cp, cs, pp, ps, dp, ds, K, B, Cin, Cout, ks, _prec(prec), int(coresident),
+                                  _stream()), "conv2_dgrad")
 
 
 # ----------------------------------------------------------------------------- loss / misc

@@ -554,7 +554,7 @@ class HipEngine(ShardEngine):
                 self._eval_pass(self.val_x, self.val_y, "Validation")
 
     # ------------------------------------------------------------------ two-stream pipeline
-    def _conv_forward(self, data, sidx, out_last) -> None:
+    def _conv_forward(self, data, sidx, out_last, coresident: bool = False) -> None:
         """Convolution stages of one batch; the last stage writes ``out_last``."""
         hip, x = self.hip, None
         for i in range(self.nc):
@@ -565,10 +565,10 @@ class HipEngine(ShardEngine):
                 hip.conv1_fwd(data, sidx, W, b, out, self.code[i], l.ksize)
             else:
                 hip.conv2_prep(W, self.wprep[i], l.ksize)
-                hip.conv2_fwd(x, W, b, out, self.code[i], l.ksize, wprep=self.wprep[i])
+                hip.conv2_fwd(x, W, b, out, self.code[i], l.ksize, wprep=self.wprep[i], coresident=coresident)
             x = out
 
-    def _conv_backward(self, data, sidx) -> None:
+    def _conv_backward(self, data, sidx, coresident: bool = False) -> None:
         hip = self.hip
         for i in range(self.nc - 1, -1, -1):
             l = self.spec.layers[i]
@@ -576,8 +576,9 @@ class HipEngine(ShardEngine):
             gW, gb = self._w(self.grads, l)
             if l.kind == "conv2pool":
                 hip.conv2_wgrad(self.dact[i], self.code[i], self.act[i - 1], gW, gb, l.ksize,
-                                scratch=self.w2_scratch[i])
-                hip.conv2_dgrad(self.dact[i], self.code[i], W, self.dact[i - 1], l.ksize, wprep=self.wprep[i])
+                                scratch=self.w2_scratch[i], coresident=coresident)
+                hip.conv2_dgrad(self.dact[i], self.code[i], W, self.dact[i - 1], l.ksize, wprep=self.wprep[i],
+                                coresident=coresident)
             else:
                 hip.conv1_wgrad(self.dact[i], self.code[i], data, sidx, gW, gb, l.ksize)
 
@@ -636,12 +637,12 @@ class HipEngine(ShardEngine):
                 nv = nv_last if s == steps - 1 else self._nv(self.B)
                 t += 1
                 self._dense_step(self._act_pp[(t - 1) & 1], self.train_y, sidx, nv, t, side)
-                with torch.cuda.stream(side):
-                    self._conv_backward(self.train_x, sidx)
+                with torch.cuda.stream(side):     # under the fused update: kernel variants that fit beside it on a CU
+                    self._conv_backward(self.train_x, sidx, coresident=True)
                     self._optim_step(t)
                     if s + 1 < steps:
                         self._conv_forward(self.train_x, self._perm_buf[e, :, (s + 1) * self.B:(s + 2) * self.B],
-                                           self._act_pp[t & 1])
+                                           self._act_pp[t & 1], coresident=True)
                 main.wait_stream(side)
             if self.val_x is not None:
                 self._eval_pass(self.val_x, self.val_y, "Validation")

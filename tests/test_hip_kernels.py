@@ -261,16 +261,19 @@ def test_conv1_wgrad(ks, B, Fm, K, prec):
         assert rel_err(db[k], dpre[k].sum(dim=(0, 2, 3))) < TOL_CONV[prec]
 
 
+@pytest.mark.parametrize("cores", [False, True])
 @pytest.mark.parametrize("ks,B,K", [(5, 32, 2), (3, 32, 2), (5, 9, 3), (5, 32, 11), (3, 7, 9)])
-def test_conv2_fwd(ks, B, K, prec):
+def test_conv2_fwd(ks, B, K, prec, cores):
     h = hip()
+    if cores and prec != "fp32":
+        pytest.skip("co-resident (small-footprint) variants exist for fp32 only")
     Cin, Cout = 32, 64
     a1 = torch.randn(K, B, Cin, 196, device=DEV).relu()
     w = slab_view(K, (Cout, Cin * ks * ks)) * 0.05
     b = slab_view(K, (Cout,)) * 0.1
     a2 = torch.empty(K, B, Cout, 49, device=DEV)
     code = torch.empty(K, B, Cout, 49, dtype=torch.uint8, device=DEV)
-    h.conv2_fwd(a1, w, b, a2, code, ks)
+    h.conv2_fwd(a1, w, b, a2, code, ks, coresident=cores)
     for k in range(K):
         pre = F.conv2d(a1[k].view(B, Cin, 14, 14), w[k].reshape(Cout, Cin, ks, ks), b[k], padding=ks // 2)
         ref = F.max_pool2d(pre.relu(), 2, 2).reshape(B, Cout, 49)
@@ -279,9 +282,13 @@ def test_conv2_fwd(ks, B, K, prec):
 
 
 # K = 2..11: batch-split blocks + partial reduction; K = 60 / 130: one block per (client, tap part)
-@pytest.mark.parametrize("ks,B,K", [(5, 32, 2), (3, 32, 2), (5, 9, 3), (5, 32, 11), (3, 7, 9), (5, 4, 60), (3, 3, 130)])
-def test_conv2_wgrad_dgrad(ks, B, K, prec):
+@pytest.mark.parametrize("cores", [False, True])
+@pytest.mark.parametrize("ks,B,K", [(5, 32, 2), (3, 32, 2), (5, 9, 3), (5, 32, 11), (3, 7, 9), (5, 4, 60), (3, 3, 130),
+                                    (5, 32, 100)])
+def test_conv2_wgrad_dgrad(ks, B, K, prec, cores):
     h = hip()
+    if cores and prec != "fp32":
+        pytest.skip("co-resident (small-footprint) variants exist for fp32 only")
     Cin, Cout = 32, 64
     a1 = torch.randn(K, B, Cin, 196, device=DEV).relu()
     w = slab_view(K, (Cout, Cin * ks * ks)) * 0.05
@@ -290,10 +297,10 @@ def test_conv2_wgrad_dgrad(ks, B, K, prec):
     dw = slab_view(K, (Cout, Cin * ks * ks))
     db = slab_view(K, (Cout,))
     da1 = torch.empty(K, B, Cin, 196, device=DEV)
-    h.conv2_wgrad(g, code, a1, dw, db, ks)
-    h.conv2_dgrad(g, code, w, da1, ks)
+    h.conv2_wgrad(g, code, a1, dw, db, ks, coresident=cores)
+    h.conv2_dgrad(g, code, w, da1, ks, coresident=cores)
     dpre = route(g, code, 7)   # [K,B,Cout,14,14]
-    for k in range(K):
+    for k in range(K if K <= 16 else 0, K, 1) if K <= 16 else range(0, K, 13):
         x = a1[k].view(B, Cin, 14, 14)
         wk = w[k].reshape(Cout, Cin, ks, ks)
         ref_w = torch.nn.grad.conv2d_weight(x, wk.shape, dpre[k], padding=ks // 2).reshape(Cout, -1)

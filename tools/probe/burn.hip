@@ -1,0 +1,49 @@
+// Synthetic co-runners for tools/overlap_probe.py: register-only loops, one wave per SIMD, no memory, no LDS.
+#include <hip/hip_runtime.h>
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+extern "C" __global__ __launch_bounds__(256) void burn_mfma_f32(float* out, int iters, float seed) {
+    f32x16 acc[4];
+    for (int j = 0; j < 4; ++j) for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    float a = seed + threadIdx.x, b = seed * 0.5f;
+    for (int i = 0; i < iters; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+    float s = 0.f;
+    for (int j = 0; j < 4; ++j) for (int e = 0; e < 16; ++e) s += acc[j][e];
+    if (s == 12345.678f) out[0] = s;
+}
+extern "C" __global__ __launch_bounds__(256) void burn_mfma_bf16(float* out, int iters, float seed) {
+    f32x16 acc[4];
+    for (int j = 0; j < 4; ++j) for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    bf16x8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(seed + e); b[e] = (__bf16)(seed * 0.5f); }
+    for (int i = 0; i < iters; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+    float s = 0.f;
+    for (int j = 0; j < 4; ++j) for (int e = 0; e < 16; ++e) s += acc[j][e];
+    if (s == 12345.678f) out[0] = s;
+}
+extern "C" __global__ __launch_bounds__(256) void burn_valu(float* out, int iters, float seed) {
+    float v[16];
+    for (int e = 0; e < 16; ++e) v[e] = seed + e + threadIdx.x;
+    for (int i = 0; i < iters; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = __builtin_fmaf(v[e], 1.0001f, 0.5f);
+    float s = 0.f;
+    for (int e = 0; e < 16; ++e) s += v[e];
+    if (s == 12345.678f) out[0] = s;
+}
+extern "C" __global__ __launch_bounds__(256) void burn_sleep(float* out, int iters, float seed) {
+    for (int i = 0; i < iters; ++i) __builtin_amdgcn_s_sleep(64);
+    if (seed == 12345.678f) out[0] = seed;
+}
+extern "C" int burn_launch(int which, int blocks, int iters, float* out, hipStream_t s) {
+    if (which == 0) hipLaunchKernelGGL(burn_mfma_f32, dim3(blocks), dim3(256), 0, s, out, iters, 1.0f);
+    else if (which == 1) hipLaunchKernelGGL(burn_mfma_bf16, dim3(blocks), dim3(256), 0, s, out, iters, 1.0f);
+    else if (which == 2) hipLaunchKernelGGL(burn_valu, dim3(blocks), dim3(256), 0, s, out, iters, 1.0f);
+    else hipLaunchKernelGGL(burn_sleep, dim3(blocks), dim3(256), 0, s, out, iters, 1.0f);
+    return (int)hipGetLastError();
+}

@@ -15,11 +15,19 @@ moves it:
 With ``encrypt=True`` every row that leaves the GPU is AES-128-ECB encrypted on the device with the
 key of its (src, dst) link and decrypted on arrival (reference: per-link AES on the socket stream,
 node_connection.py:382-386). An all-reduce has no per-link ciphertext form, so the encrypted variant
-is an all-to-all of per-link ciphertexts followed by a local sum.
+is an all-to-all of per-link ciphertexts followed by a local sum. Link keys are RANDOM: the lower rank of
+every pair draws 16 bytes from the OS and hands them to its peer point-to-point over the process group at
+start-up (:meth:`DeviceExchange.negotiate_link_keys`; the reference likewise draws a random key per link and
+sends it over the fresh socket, base_node.py:248-256). ``P2PFL_LINK_KEYS=derived`` (or a group-less exchange)
+falls back to keys derived from the scenario name - reproducible, a COST emulation only, no secrecy.
+
+A process group of ONE rank still goes through the collectives (self-split all-to-all, all-reduce, broadcast):
+that is how the RCCL path is exercised on a single-GPU box (tests/test_rccl_gpu.py).
 """
 from __future__ import annotations
 
-from typing import Dict, List, Sequence
+import os
+from typing import Dict, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -36,31 +44,73 @@ class DeviceExchange:
         self.encrypt = encrypt
         self.scenario = scenario
         self._rk_cache: Dict[tuple, torch.Tensor] = {}
+        self._link_keys: Dict[tuple, bytes] = {}     # negotiated random keys, (lo, hi) -> 16 bytes
+        self._idx_cache: Dict[tuple, torch.Tensor] = {}
+        self._send_buf: Optional[torch.Tensor] = None
+        self._crypt_buf: Dict[int, torch.Tensor] = {}
         self.bytes_sent = 0                     # payload bytes this rank pushed to peers (metrics)
+        self.bytes_encrypted = 0                # bytes that went through the link cipher (both directions)
+        if encrypt and process_group is not None and world_size > 1 and \
+                os.environ.get("P2PFL_LINK_KEYS", "random") != "derived":
+            self.negotiate_link_keys()
 
     # ------------------------------------------------------------------ link cipher
+    def negotiate_link_keys(self) -> None:
+        """Random 16-byte key per rank pair: drawn by the lower rank, sent point-to-point to the higher one."""
+        on_dev = self._backend() == "nccl"
+        mine = {r: torch.frombuffer(bytearray(os.urandom(16)), dtype=torch.uint8).clone()
+                for r in range(self.rank + 1, self.world)}
+        theirs = {r: torch.zeros(16, dtype=torch.uint8) for r in range(self.rank)}
+        if on_dev:
+            mine = {r: t.to(self.device) for r, t in mine.items()}
+            theirs = {r: t.to(self.device) for r, t in theirs.items()}
+        ops = [dist.P2POp(dist.isend, t, r, group=self.pg) for r, t in mine.items()]
+        ops += [dist.P2POp(dist.irecv, t, r, group=self.pg) for r, t in theirs.items()]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for r, t in list(mine.items()) + list(theirs.items()):
+            self._link_keys[(min(self.rank, r), max(self.rank, r))] = bytes(t.cpu().tolist())
+        self._rk_cache.clear()
+
+    def link_key(self, a: int, b: int) -> bytes:
+        k = (min(a, b), max(a, b))
+        return self._link_keys.get(k) or link_key(self.scenario, a, b)
+
     def _round_keys(self, a: int, b: int) -> torch.Tensor:
         key = (min(a, b), max(a, b))
         t = self._rk_cache.get(key)
         if t is None:
             from ..utils.aes import expand_key
-            t = torch.tensor(list(expand_key(link_key(self.scenario, a, b))), dtype=torch.uint8, device=self.device)
+            t = torch.tensor(list(expand_key(self.link_key(a, b))), dtype=torch.uint8, device=self.device)
             self._rk_cache[key] = t
         return t
 
-    def crypt(self, buf: torch.Tensor, peer: int, decrypt: bool) -> torch.Tensor:
-        """AES-128-ECB over a [rows, P] fp32 buffer with the key of link (rank, peer)."""
+    def crypt(self, buf: torch.Tensor, peer: int, decrypt: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """AES-128-ECB over a [rows, P] fp32 buffer with the key of link (rank, peer); ``out`` (same shape,
+        contiguous) receives the result, else a per-direction scratch buffer of this object is reused."""
         if buf.numel() == 0:
             return buf
-        raw = buf.view(torch.uint8).reshape(-1)
+        self.bytes_encrypted += buf.numel() * 4
+        raw = buf.contiguous().view(torch.uint8).reshape(-1)
         if buf.is_cuda:
             from ..ops import hip
-            out = torch.empty_like(raw)
-            hip.aes128_ecb(raw, out, self._round_keys(self.rank, peer), decrypt)
-            return out.view(torch.float32).reshape(buf.shape)
+            if out is None:
+                scratch = self._crypt_buf.get(int(decrypt))
+                if scratch is None or scratch.numel() < raw.numel():
+                    scratch = self._crypt_buf[int(decrypt)] = torch.empty(raw.numel(), dtype=torch.uint8, device=buf.device)
+                dst = scratch[:raw.numel()]
+            else:
+                dst = out.view(torch.uint8).reshape(-1)
+            hip.aes128_ecb(raw, dst, self._round_keys(self.rank, peer), decrypt)
+            return dst.view(torch.float32).reshape(buf.shape)
         from ..utils.aes import ecb_host
-        data = ecb_host(link_key(self.scenario, self.rank, peer), raw.numpy().tobytes(), decrypt)
-        return torch.frombuffer(bytearray(data), dtype=torch.float32).reshape(buf.shape)
+        data = ecb_host(self.link_key(self.rank, peer), raw.numpy().tobytes(), decrypt)
+        res = torch.frombuffer(bytearray(data), dtype=torch.float32).reshape(buf.shape)
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
 
     def _backend(self) -> str:
         return dist.get_backend(self.pg)
@@ -88,16 +138,25 @@ class DeviceExchange:
         """Send ``params[send_rows[r]]`` to every peer r, receive ``recv_counts[r]`` rows from it into
         ``staging`` (peer-major order). Returns the number of rows received."""
         n_recv = int(sum(recv_counts))
-        if self.world == 1:
+        if self.pg is None:            # no process group at all: a single shard, nothing to move
             return 0
         P = params.shape[1]
         send_counts = [len(l) for l in send_rows]
-        flat = [int(j) for l in send_rows for j in l]
-        # ONE gather builds the peer-major send buffer (rows of a 26 MB model: no per-peer temporaries)
-        if flat:
-            send_cat = params.index_select(0, torch.as_tensor(flat, device=self.device))
-        else:
-            send_cat = params.new_zeros(0, P)
+        n_send = sum(send_counts)
+        # ONE gather builds the peer-major send buffer (rows of a 26 MB model: no per-peer temporaries); the index
+        # tensor of a plan and the buffer itself are kept, so a steady-state round allocates nothing
+        key = tuple(tuple(int(j) for j in l) for l in send_rows)
+        idx = self._idx_cache.get(key)
+        if idx is None:
+            if len(self._idx_cache) > 64:
+                self._idx_cache.clear()
+            idx = self._idx_cache[key] = torch.as_tensor([j for l in key for j in l], dtype=torch.long,
+                                                         device=self.device)
+        if self._send_buf is None or self._send_buf.shape[0] < max(n_send, 1) or self._send_buf.shape[1] != P:
+            self._send_buf = torch.empty(max(n_send, 1), P, device=self.device)
+        send_cat = self._send_buf[:n_send]
+        if n_send:
+            torch.index_select(params, 0, idx, out=send_cat)
         self.bytes_sent += send_cat.numel() * 4
         if self.encrypt:
             off = 0
@@ -106,6 +165,7 @@ class DeviceExchange:
                     send_cat[off:off + c] = self.crypt(send_cat[off:off + c], r, decrypt=False)
                     off += c
         if self._backend() == "nccl":
+            # plaintext rows land straight in the staging buffer the reduce kernel reads; ciphertext in a scratch
             recv_cat = staging[:n_recv] if not self.encrypt else torch.empty(n_recv, P, device=self.device)
             dist.all_to_all_single(recv_cat, send_cat, output_split_sizes=list(recv_counts),
                                    input_split_sizes=send_counts, group=self.pg)
@@ -130,7 +190,7 @@ class DeviceExchange:
             off = 0
             for r in range(self.world):
                 if recv_counts[r]:
-                    staging[off:off + recv_counts[r]] = self.crypt(recv_cat[off:off + recv_counts[r]].contiguous(), r, True)
+                    self.crypt(recv_cat[off:off + recv_counts[r]], r, True, out=staging[off:off + recv_counts[r]])
                     off += recv_counts[r]
         elif recv_cat.data_ptr() != staging.data_ptr():
             staging[:n_recv] = recv_cat
@@ -138,9 +198,9 @@ class DeviceExchange:
 
     def allreduce_partial(self, partial: torch.Tensor) -> torch.Tensor:
         """Sum of every rank's [1, P] partial (weights already normalised by the global weight sum)."""
-        if self.world == 1:
+        if self.pg is None:
             return partial
-        self.bytes_sent += partial.numel() * 4
+        self.bytes_sent += partial.numel() * 4 * (self.world > 1)
         if not self.encrypt:
             if self._backend() != "nccl" and partial.is_cuda:
                 host = partial.cpu()
@@ -149,16 +209,25 @@ class DeviceExchange:
             else:
                 dist.all_reduce(partial, group=self.pg)
             return partial
-        enc = [self.crypt(partial, r, False) if r != self.rank else partial for r in range(self.world)]
+        enc = [self.crypt(partial, r, False).clone() if r != self.rank else partial for r in range(self.world)]
         outs = [torch.empty_like(partial) for _ in range(self.world)]
         self.all_to_all(outs, enc)
-        return sum(self.crypt(o, r, True) if r != self.rank else o for r, o in enumerate(outs))
+        total = torch.zeros_like(partial)
+        for r, o in enumerate(outs):
+            total += self.crypt(o, r, True) if r != self.rank else o
+        return total
 
     def broadcast(self, t: torch.Tensor, src: int) -> torch.Tensor:
-        if self.world > 1:
-            dist.broadcast(t, src=src, group=self.pg)
+        """In-place broadcast of ``t`` from rank ``src`` (initial-model diffusion, node.py:298-299,702-724)."""
+        if self.pg is not None:
+            if self._backend() != "nccl" and t.is_cuda:
+                host = t.cpu()
+                dist.broadcast(host, src=src, group=self.pg)
+                t.copy_(host)
+            else:
+                dist.broadcast(t, src=src, group=self.pg)
         return t
 
     def barrier(self) -> None:
-        if self.world > 1:
+        if self.pg is not None:
             dist.barrier(group=self.pg)

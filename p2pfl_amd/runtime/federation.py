@@ -93,13 +93,22 @@ class BatchedFederation:
         self.rng = random.Random(seed)                            # shared by all ranks (same seed)
         self.comm = DeviceExchange(rank, world_size, process_group, self.device, encrypt, scenario)
         self.staging: Optional[torch.Tensor] = None
+        self._partial: Optional[torch.Tensor] = None
         self._plan_cache: Dict[bytes, tuple] = {}
         self.trace = os.environ.get("P2PFL_TRACE", "0") not in ("", "0")   # roctx ranges around the phases
         self.reports: List[RoundReport] = []
 
     # ------------------------------------------------------------------ setup
-    def init_params(self, seed: Optional[int] = None) -> None:
+    def init_params(self, seed: Optional[int] = None, start_node: int = 0) -> None:
+        """Initial-model diffusion (node.py:298-299,372-379,702-724): every node of the scenario starts from the
+        START node's weights. The rank that owns the start node initialises it; with a process group its row is
+        broadcast (RCCL) to all ranks instead of relying on every rank drawing the same numbers."""
         self.engine.init_params(seed=seed, identical=True)
+        if self.pg is not None:
+            src = int(self.owner[start_node])
+            row = self.engine.params[start_node - self.local.start if src == self.rank else 0].clone()
+            self.comm.broadcast(row, src)
+            self.engine.params.copy_(row.unsqueeze(0).expand(self.n_local, -1))
 
     def set_local_data(self, train_x, train_y, val_x=None, val_y=None, test_x=None, test_y=None,
                        n_train_all: Optional[Sequence[int]] = None) -> None:
@@ -111,6 +120,16 @@ class BatchedFederation:
             self.weights[:] = train_x.shape[1]
         else:
             self.weights[:] = np.asarray(n_train_all, dtype=np.float64)
+
+    def fast_forward(self, first_round: int) -> None:
+        """Resume at ``first_round``: the faults of the rounds already done are applied (with the clock moving as
+        if those rounds had run), the round and per-round shuffle counters continue - no training."""
+        for r in range(self.round, first_round):
+            self.membership.apply_round(r)
+            self.membership.advance(self.membership.period)
+        self.alive = self.membership.alive().copy()
+        self.round = first_round
+        self.engine._perm_calls = first_round
 
     def schedule_fault(self, round_idx: int, action: str, node: int, peer: Optional[int] = None) -> None:
         """Deterministic churn applied at the start of a round: ``kill`` / ``revive`` / ``pause`` / ``resume``
@@ -154,7 +173,17 @@ class BatchedFederation:
         """Exchange plan of this rank (see parallel/planner.py) in the tuple form ``aggregate`` caches."""
         ep = plan_exchange(train_sets, adopt, self.owner, self.weights, self.rank, self.world, self.local)
         if ep.mode == "allreduce":
-            return ("allreduce", ep.local_sources, ep.local_weights, ep.local_dests)
+            lo, dev = self.local.start, self.device
+            plan = idx = None
+            if ep.local_sources:
+                i32 = dict(dtype=torch.int32, device=dev)
+                plan = AggregationPlan(torch.tensor([0, len(ep.local_sources)], **i32),
+                                       torch.tensor([j - lo for j in ep.local_sources], **i32),
+                                       torch.tensor(ep.local_weights, dtype=torch.float32, device=dev),
+                                       torch.tensor([0, 1], **i32), torch.tensor([0], **i32), 1)
+            if ep.local_dests:
+                idx = torch.tensor([d - lo for d in ep.local_dests], device=dev)
+            return ("allreduce", ep.local_sources, ep.local_weights, ep.local_dests, plan, idx)
         return ("rows", ep.send_lists, ep.recv_lists, build_plan(ep.groups), ep.n_recv)
 
     # ------------------------------------------------------------------ exchange
@@ -222,21 +251,18 @@ class BatchedFederation:
     def _run_exchange(self, cached, out) -> int:
         eng = self.engine
         if cached[0] == "allreduce":
-            _, loc_src, loc_w, loc_dst = cached
-            lo = self.local.start
+            plan, idx = cached[4], cached[5]       # device-side plan / destination rows, built once per structure
             P = eng.layout.row_stride
-            partial = torch.zeros(1, P, device=self.device)
-            if loc_src:
-                plan = AggregationPlan(torch.tensor([0, len(loc_src)], dtype=torch.int32, device=self.device),
-                                       torch.tensor([j - lo for j in loc_src], dtype=torch.int32, device=self.device),
-                                       torch.tensor(loc_w, dtype=torch.float32, device=self.device),
-                                       torch.tensor([0, 1], dtype=torch.int32, device=self.device),
-                                       torch.tensor([0], dtype=torch.int32, device=self.device), 1)
-                run_plan(eng.params, None, partial, plan)
+            if self._partial is None or self._partial.shape[1] != P:
+                self._partial = torch.zeros(1, P, device=self.device)
+            partial = self._partial
+            if plan is not None:
+                run_plan(eng.params, None, partial, plan)      # (the reduce kernel overwrites its destination rows)
+            else:
+                partial.zero_()
             partial = self.comm.allreduce_partial(partial)
-            if loc_dst:
-                idx = torch.tensor([d - lo for d in loc_dst], device=self.device)
-                out[idx] = partial.expand(len(loc_dst), -1)
+            if idx is not None:
+                out[idx] = partial.expand(idx.numel(), -1)
             eng.swap_slabs()
             return self.world - 1
         _, send_lists, recv_lists, plan, n_recv = cached

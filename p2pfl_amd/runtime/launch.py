@@ -85,7 +85,8 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if device == "cuda" else "gloo", rank=rank, world_size=world)
+        dist.init_process_group("nccl" if device == "cuda" else "gloo", rank=rank, world_size=world,
+                                **({"device_id": dev} if device == "cuda" else {}))
         pg = dist.group.WORLD
 
     parts = load_participants(config_dir)
@@ -105,7 +106,7 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
     scenario = p0["scenario_args"]["name"] or os.path.basename(os.path.normpath(config_dir))
     federation = p0["scenario_args"]["federation"]
     roles = [p["device_args"]["role"] for p in parts]
-    rounds = rounds or int(p0["scenario_args"]["rounds"])
+    total_rounds = rounds or int(p0["scenario_args"]["rounds"])     # of the whole experiment (a resumed run does the rest)
     epochs = int(p0["training_args"]["epochs"])
 
     fed = BatchedFederation(spec, adjacency_from_participants(parts), federation=federation, roles=roles, device=dev,
@@ -118,22 +119,48 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
     # data shards of the local nodes (real files when present, synthetic otherwise)
     shards = [build_dataset_and_model(key[0], key[1], i, n, root_dir)[0] for i in fed.local]
 
+    # rows per split: the smallest shard of the WHOLE scenario (splits can differ by a row between nodes), agreed
+    # across ranks so that every rank stacks the same shape
+    lens = [[len(t) if t is not None else 0 for t in s.tensors()] for s in shards]
+    mins = torch.tensor([min(l[i] for l in lens) for i in range(6)], dtype=torch.int64)
+    n_train_local = torch.tensor([l[0] for l in lens], dtype=torch.int64)
+    n_train_all = n_train_local
+    if pg is not None:
+        work = mins.to(dev) if device == "cuda" else mins
+        dist.all_reduce(work, op=dist.ReduceOp.MIN, group=pg)
+        mins = work.cpu()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, n_train_local.tolist(), group=pg)
+        n_train_all = torch.tensor([v for g in gathered for v in g], dtype=torch.int64)
+
     def stack(idx):
         ts = [s.tensors()[idx] for s in shards]
         if ts[0] is None:
             return None
-        m = min(len(t) for t in ts)                  # (splits can differ by a row between nodes)
-        return torch.stack([t[:m] for t in ts])
-    fed.init_params()
-    fed.set_local_data(*(stack(i) for i in range(6)))
+        return torch.stack([t[:int(mins[idx])] for t in ts])
+    fed.init_params(start_node=next((i for i, p in enumerate(parts) if p["device_args"].get("start")), 0))
+    # FedAvg weights = the true per-node training-set sizes of the whole scenario (node.py:447)
+    fed.set_local_data(*(stack(i) for i in range(6)), n_train_all=n_train_all.tolist())
     first_round = 0
     if resume:
-        # resume = every node restarts from its checkpoint (the reference payload bytes)
+        # resume = every node restarts from its checkpoint (the reference payload bytes) and the
+        # experiment continues where it stopped: round counter, shuffle counter, roles (the SDFL leader) and the
+        # membership state (faults scheduled for the rounds already done are replayed without training)
         from ..learning.codec import load_checkpoint
+        metas = []
         for k, i in enumerate(fed.local):
             arrays, _, _, meta = load_checkpoint(os.path.join(resume, f"participant_{i}_final.ckpt"))
             fed.engine.set_arrays(k, arrays)
+            metas.append(meta or {})
             first_round = max(first_round, int((meta or {}).get("round", 0)))
+        roles_saved = {int(i): m.get("role") for i, m in zip(fed.local, metas) if m.get("role")}
+        if pg is not None:
+            allr = [None] * world
+            dist.all_gather_object(allr, roles_saved, group=pg)
+            roles_saved = {k: v for d in allr for k, v in d.items()}
+        for i, role in roles_saved.items():
+            fed.roles[i] = role
+        fed.fast_forward(first_round)
 
     fed.prepare()       # captured graphs / exchange plan before round 0 (models and counters stay as they are)
     log_root = os.path.join(p0["tracking_args"].get("log_dir") or "logs", scenario)
@@ -160,7 +187,10 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
 
     t0 = time.time()
     total_samples = 0
-    for r in range(first_round, first_round + rounds):
+    rounds = max(total_rounds - first_round, 0)
+    if rounds == 0:
+        logging.warning("resumed at round %d of %d: nothing left to do", first_round, total_rounds)
+    for r in range(first_round, total_rounds):
         rep = fed.run_round()
         total_samples += rep.train_samples
         test = fed.engine.stats["Test"].summary()
@@ -192,7 +222,7 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
     for lg in loggers.values():
         lg.finalize()
     summary = {"scenario": scenario, "rank": rank, "world": world, "nodes": n, "local_nodes": fed.n_local,
-               "rounds": rounds, "seconds": elapsed, "rounds_per_sec": rounds / elapsed,
+               "rounds": rounds, "seconds": elapsed, "rounds_per_sec": rounds / max(elapsed, 1e-9),
                "samples_per_sec": total_samples / elapsed, "final_test_accuracy": float(final["accuracy"].mean()),
                "final_test_loss": float(final["loss"].mean()), "first_round": first_round,
                "membership_events": [[round(t, 3), what, node] for t, what, node in fed.membership.events]}
@@ -210,7 +240,8 @@ def main(argv=None):
     ap.add_argument("--device", default="auto", choices=["auto", "cuda", "cpu"])
     ap.add_argument("--encrypt", action="store_true")
     ap.add_argument("--save-models", action="store_true")
-    ap.add_argument("--rounds", type=int, default=None)
+    ap.add_argument("--rounds", type=int, default=None,
+                    help="total rounds of the experiment (default: scenario_args.rounds); a --resume run does the remaining ones")
     ap.add_argument("--resume", default=None, help="directory with participant_<i>_final.ckpt files to start from")
     a = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO)

@@ -95,7 +95,8 @@ def test_batched_launcher_faults_checkpoints_and_resume(tmp_path):
         p["network_args"]["neighbors"] = " ".join(f"127.0.0.1:{45000 + j}" for j in ((i - 1) % 4, (i + 1) % 4))
         p["scenario_args"]["name"] = "scen"
         json.dump(p, open(path, "w"))
-    json.dump([{"round": 1, "action": "kill", "node": 3}], open(os.path.join(cdir, "faults.json"), "w"))
+    json.dump([{"round": 1, "action": "kill", "node": 3}, {"round": 2, "action": "revive", "node": 3}],
+              open(os.path.join(cdir, "faults.json"), "w"))
     s1 = run_scenario(cdir, device="cpu", save_models=True)
     assert s1["rounds"] == 2 and s1["first_round"] == 0 and [e[1:] for e in s1["membership_events"]] == [["kill", 3]]
     log3 = open(tmp_path / "logs" / "scen" / "participant_3.log").read()
@@ -104,9 +105,12 @@ def test_batched_launcher_faults_checkpoints_and_resume(tmp_path):
     assert "Federation/RoundSeconds" in rows and "Federation/Phase_train_seconds" in rows
     ck = tmp_path / "logs" / "scen" / "participant_0_final.ckpt"
     assert ck.exists() and json.load(open(str(ck) + ".json"))["round"] == 2
-    os.remove(os.path.join(cdir, "faults.json"))
-    s2 = run_scenario(cdir, device="cpu", rounds=1, resume=str(tmp_path / "logs" / "scen"))
+    # the resumed run does what is left of a 3-round experiment; the fault schedule (absolute rounds) continues:
+    # the kill of round 1 is replayed without training, the revival of round 2 happens in the resumed round
+    s2 = run_scenario(cdir, device="cpu", rounds=3, resume=str(tmp_path / "logs" / "scen"))
     assert s2["first_round"] == 2 and s2["rounds"] == 1
+    assert [e[1:] for e in s2["membership_events"]] == [["kill", 3], ["revive", 3]]
+    assert "round 2 role aggregator alive True" in open(tmp_path / "logs" / "scen" / "participant_3.log").read()
     # resumed from trained weights: the very first evaluation is already good
     first_eval = [l for l in open(tmp_path / "logs" / "scen" / "participant_1.log").read().splitlines() if "round 2 " in l][0]
     assert float(first_eval.split("test_acc ")[1].split()[0]) > 0.5

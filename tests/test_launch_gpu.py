@@ -43,9 +43,9 @@ def test_scenario_on_the_hip_engine(tmp_path, dataset, model, federation, topolo
     rows = open(logs / "metrics" / "participant_0" / "metrics.csv").read()
     assert "Test/Loss" in rows and "Federation/Phase_train_seconds" in rows
     assert (logs / "participant_0_final.ckpt").exists()
-    os.remove(os.path.join(cdir, "faults.json"))
-    s2 = run_scenario(cdir, device="cuda", rounds=1, resume=str(logs))
-    assert s2["first_round"] == 2 and s2["rounds"] == 1
+    # (the schedule stays: the resumed run replays the kill of round 1 without training and does round 2 of 3)
+    s2 = run_scenario(cdir, device="cuda", rounds=3, resume=str(logs))
+    assert s2["first_round"] == 2 and s2["rounds"] == 1 and [e[1:] for e in s2["membership_events"]] == [["kill", 3]]
     if dataset == "MNIST":       # synthetic MNIST-shaped shards are learnable: resumed weights evaluate well at once
         first_eval = [l for l in open(logs / "participant_1.log").read().splitlines() if "round 2 " in l][0]
         assert float(first_eval.split("test_acc ")[1].split()[0]) > 0.5

@@ -56,8 +56,12 @@ def eager_baseline_samples_per_sec():
 PRESETS = {
     "cnn10-fully": dict(model="mnist-cnn", nodes_per_gpu=10, split_nodes=10, topology="fully"),
     "femnist50-ring": dict(model="femnist-cnn", nodes_per_gpu=50, split_nodes=50, topology="ring"),
+    # config #4: AES-128 per-link encryption of every row that crosses a (virtual) device boundary + 10 % churn with the
+    # reference's failure semantics (dead nodes are waited for AGGREGATION_TIMEOUT on the virtual clock, then evicted
+    # NODE_TIMEOUT later; half of the victims die mid-round, after training). On ONE GPU the 100 nodes are split into
+    # 2 virtual devices so that the exchange takes the inter-GPU path (gather -> AES -> staging -> AES^-1 -> reduce).
     "cnn100-encrypted-churn": dict(model="mnist-cnn", nodes_per_gpu=100, split_nodes=100, topology="random",
-                                   encrypt=True, churn=0.1),
+                                   encrypt=True, churn=0.1, virtual_devices=2),
     "mlp100-random": dict(model="mnist-mlp", nodes_per_gpu=100, split_nodes=100, topology="random"),   # extra: the MLP
     "femnist1000-star": dict(model="femnist-cnn", nodes_per_gpu=1000, split_nodes=1000, topology="star",
                              federation="CFL"),
@@ -104,6 +108,8 @@ def main() -> None:
                     help="data shards are sized as in an N-node split of MNIST (reference mnist.py:100-118)")
     ap.add_argument("--churn", type=float, default=0.0,
                     help="fraction of nodes killed one round after warm-up and revived two rounds later")
+    ap.add_argument("--virtual-devices", type=int, default=1,
+                    help="1-GPU runs: split the nodes into virtual devices whose exchange takes the inter-GPU path")
     ap.add_argument("--config", default=None, choices=sorted(PRESETS),
                     help="one of the other BASELINE.json configurations (overrides the flags it names)")
     args = ap.parse_args()
@@ -133,7 +139,8 @@ def main() -> None:
     fed = BatchedFederation(spec, topo, federation=args.federation, device=device, engine=args.impl,
                             batch_size=args.batch_size, epochs=args.epochs, seed=args.seed, rank=rank,
                             world_size=world, process_group=pg, encrypt=args.encrypt,
-                            use_graph=not args.no_graph, overlap=not args.no_overlap, precision=args.dtype)
+                            use_graph=not args.no_graph, overlap=not args.no_overlap, precision=args.dtype,
+                            instant_detection=args.churn <= 0, virtual_devices=args.virtual_devices)
     # shard sizes of the named 100-node split (reference mnist.py:100-118)
     n_tr, n_va, n_te = reference_shard_sizes(args.split_nodes)
     tx, ty, vx, vy, ex, ey = synthetic_shards(fed.n_local, n_tr, n_va, n_te, spec.num_classes, seed=args.seed,
@@ -150,8 +157,8 @@ def main() -> None:
     if args.churn > 0:
         import random
         victims = random.Random(args.seed).sample(range(1, n_nodes), max(1, int(args.churn * n_nodes)))
-        for v in victims:
-            fed.schedule_fault(args.warmup + 1, "kill", v)
+        for n_v, v in enumerate(victims):       # every other victim dies in the middle of its round (trained, never delivers)
+            fed.schedule_fault(args.warmup + 1, "kill", v, phase="mid" if n_v % 2 else "start")
             fed.schedule_fault(args.warmup + 3, "revive", v)
     fed.prepare()                          # graph capture / lazy loading / planning happen here even with --warmup 0
     for _ in range(args.warmup):
@@ -160,9 +167,13 @@ def main() -> None:
     t0 = time.perf_counter()
     samples = 0
     last = None
+    enc_bytes = timeouts = rows = 0
     for _ in range(args.steps):
         last = fed.run_round(sync_timing=False)
         samples += last.train_samples
+        enc_bytes += last.encrypted_bytes
+        timeouts += last.timeouts
+        rows += last.exchanged_rows
     sync()
     elapsed = time.perf_counter() - t0
 
@@ -200,7 +211,9 @@ def main() -> None:
                 "global_batch": args.batch_size * n_nodes, "batch_per_node": args.batch_size,
                 "train_samples_per_node": n_tr, "optimizer_steps_per_round": steps_per_epoch * args.epochs,
                 "seq_len": None, "parallelism": f"fdp{world}x{fed.n_local}", "encrypt": args.encrypt,
-                "churn": args.churn, "preset": args.config,
+                "churn": args.churn, "preset": args.config, "virtual_devices": args.virtual_devices,
+                "encrypted_bytes": enc_bytes, "exchanged_rows": rows, "aggregation_timeouts": timeouts,
+                "membership_events": [[round(t, 1), what, node] for t, what, node in fed.membership.events][:64],
                 "last_test_accuracy_mean": None if last is None or last.test_accuracy is None
                 else float(last.test_accuracy.mean()),
             },

@@ -86,11 +86,14 @@ class DeviceExchange:
             self._rk_cache[key] = t
         return t
 
-    def crypt(self, buf: torch.Tensor, peer: int, decrypt: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def crypt(self, buf: torch.Tensor, peer: int, decrypt: bool, out: Optional[torch.Tensor] = None,
+              local: Optional[int] = None) -> torch.Tensor:
         """AES-128-ECB over a [rows, P] fp32 buffer with the key of link (rank, peer); ``out`` (same shape,
-        contiguous) receives the result, else a per-direction scratch buffer of this object is reused."""
+        contiguous) receives the result, else a per-direction scratch buffer of this object is reused.
+        ``local``: the near end of the link when it is not this rank (virtual devices sharing one GPU)."""
         if buf.numel() == 0:
             return buf
+        me = self.rank if local is None else local
         self.bytes_encrypted += buf.numel() * 4
         raw = buf.contiguous().view(torch.uint8).reshape(-1)
         if buf.is_cuda:
@@ -102,10 +105,10 @@ class DeviceExchange:
                 dst = scratch[:raw.numel()]
             else:
                 dst = out.view(torch.uint8).reshape(-1)
-            hip.aes128_ecb(raw, dst, self._round_keys(self.rank, peer), decrypt)
+            hip.aes128_ecb(raw, dst, self._round_keys(me, peer), decrypt)
             return dst.view(torch.float32).reshape(buf.shape)
         from ..utils.aes import ecb_host
-        data = ecb_host(self.link_key(self.rank, peer), raw.numpy().tobytes(), decrypt)
+        data = ecb_host(self.link_key(me, peer), raw.numpy().tobytes(), decrypt)
         res = torch.frombuffer(bytearray(data), dtype=torch.float32).reshape(buf.shape)
         if out is not None:
             out.copy_(res)

@@ -78,7 +78,8 @@ class ExchangePlan:
 
 
 def plan_exchange(train_sets: Dict[int, Sequence[int]], adopt: Dict[int, int], owner: np.ndarray,
-                  weights: Sequence[float], rank: int, world: int, local: range) -> ExchangePlan:
+                  weights: Sequence[float], rank: int, world: int, local: range,
+                  allow_allreduce: bool = True) -> ExchangePlan:
     """Exchange plan of ``rank`` for one round structure.
 
     train_sets: aggregating node -> contributor node ids; adopt: waiting node -> aggregating node.
@@ -86,7 +87,7 @@ def plan_exchange(train_sets: Dict[int, Sequence[int]], adopt: Dict[int, int], o
     local_set = set(local)
     lo = local.start
     keys = {tuple(ts) for ts in train_sets.values()}
-    if world > 1 and len(keys) == 1:
+    if world > 1 and len(keys) == 1 and allow_allreduce:
         contributors = list(next(iter(keys)))
         dests = sorted(set(train_sets) | set(adopt))
         tot = float(sum(weights[j] for j in contributors))

@@ -14,7 +14,10 @@ which reproduces the per-node round of the reference (``Node.__train_step`` /
 * trainers / proxies / idle nodes adopt the model of an aggregating neighbour
   (aggregator.py:119-123); in SDFL the aggregator role moves to a random neighbour after every
   round (node.py:648-650,676-686);
-* dead nodes (fault injection / heartbeat eviction) drop out of every train set and stop training.
+* a dead node (fault injection) stops training at once but stays in its neighbours' train sets until the
+  heartbeat table evicts it ``NODE_TIMEOUT`` later (heartbeater.py:88-101): meanwhile every aggregator that expects
+  its model waits ``AGGREGATION_TIMEOUT`` on the (virtual) clock and then averages the subset that did arrive
+  (aggregator.py:47-76,181-208) - all those partial aggregations are groups of ONE launch of the reduce kernel.
 
 Model exchange is *not* message passing: rows of co-resident neighbours are read in place by
 the fused reduce kernel; rows owned by other GPUs are moved with RCCL over xGMI — a single
@@ -54,6 +57,8 @@ class RoundReport:
     test_accuracy: Optional[torch.Tensor] = None
     train_loss: Optional[torch.Tensor] = None
     exchanged_rows: int = 0
+    timeouts: int = 0                # aggregators that gave up on a missing contributor (partial aggregation)
+    encrypted_bytes: int = 0         # bytes that went through the link cipher in this round
 
 
 class BatchedFederation:
@@ -62,7 +67,8 @@ class BatchedFederation:
                  rank: int = 0, world_size: int = 1, process_group=None, encrypt: bool = False,
                  scenario: str = "scenario", persist_optimizer: bool = False, use_graph: bool = True,
                  overlap: bool = True, heartbeat_period: float = 4.0, node_timeout: float = 20.0,
-                 instant_detection: bool = True, precision: Optional[str] = None):
+                 instant_detection: bool = True, precision: Optional[str] = None,
+                 aggregation_timeout: float = 60.0, virtual_devices: int = 1):
         self.spec = spec
         self.adj = np.asarray(topology, dtype=np.float32)
         self.N = self.adj.shape[0]
@@ -87,11 +93,22 @@ class BatchedFederation:
                                                   if engine != "eager" else {}))
         # membership of ALL nodes of the scenario (every rank applies the same deterministic schedule)
         self.membership = VirtualMembership(self.N, heartbeat_period, node_timeout, instant=instant_detection)
-        self.alive = np.ones(self.N, dtype=bool)
+        self.alive = np.ones(self.N, dtype=bool)                # the node's process is up (it evaluates / trains)
+        self.believed = np.ones(self.N, dtype=bool)             # its neighbours still count it into their train sets
+        self.delivered = np.ones(self.N, dtype=bool)            # its model of this round reaches its neighbours
+        self.aggregation_timeout = float(aggregation_timeout)
+        self.external_clock = False                             # a FederationHost drives the membership clock itself
+        self.pre_aggregate_hook = None                          # callables (fed) -> None set by a FederationHost
+        self.post_aggregate_hook = None
         self.weights = np.zeros(self.N, dtype=np.float64)       # training samples per node
         self.round = 0
         self.rng = random.Random(seed)                            # shared by all ranks (same seed)
         self.comm = DeviceExchange(rank, world_size, process_group, self.device, encrypt, scenario)
+        # >= 2: the nodes of this GPU are split into "virtual devices"; rows that cross from one to another take the
+        # inter-GPU path of a multi-GPU job (gather -> link cipher -> staging -> decrypt -> reduce over local +
+        # staged rows) although they never leave the card - config #4 (encrypted exchange) on a one-GPU box
+        self.virtual_devices = int(virtual_devices) if world_size == 1 else 1
+        self._vd_cache: Dict[bytes, tuple] = {}
         self.staging: Optional[torch.Tensor] = None
         self._partial: Optional[torch.Tensor] = None
         self._plan_cache: Dict[bytes, tuple] = {}
@@ -125,39 +142,52 @@ class BatchedFederation:
         """Resume at ``first_round``: the faults of the rounds already done are applied (with the clock moving as
         if those rounds had run), the round and per-round shuffle counters continue - no training."""
         for r in range(self.round, first_round):
-            self.membership.apply_round(r)
+            self.membership.apply_round(r, None)
             self.membership.advance(self.membership.period)
-        self.alive = self.membership.alive().copy()
+        self._sync_membership()
         self.round = first_round
         self.engine._perm_calls = first_round
 
-    def schedule_fault(self, round_idx: int, action: str, node: int, peer: Optional[int] = None) -> None:
-        """Deterministic churn applied at the start of a round: ``kill`` / ``revive`` / ``pause`` / ``resume``
-        of a node, ``drop_link`` / ``restore_link`` of the edge (node, peer); see runtime/membership.py."""
-        self.membership.schedule(round_idx, action, node, peer)
+    def schedule_fault(self, round_idx: int, action: str, node: int, peer: Optional[int] = None,
+                       phase: str = "start") -> None:
+        """Deterministic churn: ``kill`` / ``revive`` / ``pause`` / ``resume`` of a node, ``drop_link`` /
+        ``restore_link`` of the edge (node, peer), at the start of a round or in the middle of it (``phase="mid"``:
+        after local training, before the exchange); see runtime/membership.py."""
+        self.membership.schedule(round_idx, action, node, peer, phase)
 
     # ------------------------------------------------------------------ per-round structure
     def neighbors(self, i: int) -> List[int]:
         return [int(j) for j in np.nonzero(self.adj[i])[0] if j != i and self.membership.link_up(i, int(j))]
 
     def train_set(self, i: int) -> List[int]:
+        """What node i EXPECTS to aggregate: its direct neighbours that the heartbeat table still lists, plus
+        itself (node.py:411-422,537-548)."""
         if not self.alive[i]:
             return []
-        return sorted([j for j in self.neighbors(i) if self.alive[j]] + [i])
+        return sorted([j for j in self.neighbors(i) if self.believed[j]] + [i])
+
+    def _present(self, j: int) -> bool:
+        return bool(self.alive[j] and self.delivered[j])
 
     def _round_structure(self):
-        """(train_sets of aggregating nodes, adopt map of waiting nodes) for the current state."""
+        """(train_sets of aggregating nodes, adopt map of waiting nodes) for the current state. A train set here is
+        what ARRIVES: expected members that are down (not yet evicted) or died mid-round are missing, the
+        aggregator times out and averages the rest (``self.timed_out`` lists those aggregators)."""
         train_sets: Dict[int, List[int]] = {}
         adopt: Dict[int, int] = {}
+        self.timed_out: List[int] = []
         for i in range(self.N):
-            if self.alive[i] and Role.aggregates(self.roles[i]):
-                # contributors: live members of the train set that hold a model to contribute
+            if self._present(i) and Role.aggregates(self.roles[i]):
+                # contributors: members of the train set that hold a model to contribute
                 # (proxy/idle nodes never add their own model, node.py:492-524)
-                ts = [j for j in self.train_set(i) if self.roles[j] not in (Role.PROXY, Role.IDLE)]
+                expected = [j for j in self.train_set(i) if self.roles[j] not in (Role.PROXY, Role.IDLE)]
+                ts = [j for j in expected if self._present(j)]
+                if len(ts) < len(expected):
+                    self.timed_out.append(i)
                 train_sets[i] = ts
         for i in range(self.N):
-            if self.alive[i] and Role.waits(self.roles[i]):
-                aggs = [j for j in self.neighbors(i) if self.alive[j] and j in train_sets]
+            if self._present(i) and Role.waits(self.roles[i]):
+                aggs = [j for j in self.neighbors(i) if self._present(j) and j in train_sets]
                 if aggs:
                     adopt[i] = aggs[0]
         return train_sets, adopt
@@ -165,6 +195,8 @@ class BatchedFederation:
     def _structure_key(self) -> bytes:
         h = hashlib.sha1()
         h.update(self.alive.tobytes())
+        h.update(self.believed.tobytes())
+        h.update(self.delivered.tobytes())
         h.update(repr(sorted(self.membership.dropped)).encode())
         h.update("|".join(self.roles).encode())
         return h.digest()
@@ -198,9 +230,19 @@ class BatchedFederation:
                                        [len(l) for l in recv_lists], self.staging)
 
     # ------------------------------------------------------------------ the round
-    def _apply_faults(self) -> None:
-        self.membership.apply_round(self.round)
-        self.alive = self.membership.alive().copy()
+    def _apply_faults(self, phase: str = "start") -> None:
+        before = self.membership.running().copy()
+        self.membership.apply_round(self.round, phase)
+        self._sync_membership()
+        if phase == "start":
+            self.delivered[:] = True
+        else:
+            # a node that went down in the middle of the round trained for nothing: its model never arrives
+            self.delivered &= ~(before & ~self.membership.running())
+
+    def _sync_membership(self) -> None:
+        self.alive = self.membership.running().copy()
+        self.believed = self.membership.believed().copy()
 
     def _range(self, name: str):
         """roctx range (visible in rocprofv3 --marker-trace) when P2PFL_TRACE=1."""
@@ -212,6 +254,8 @@ class BatchedFederation:
     def aggregate(self) -> int:
         """Exchange + FedAvg for the current membership/roles. Returns #rows received from peers."""
         eng = self.engine
+        if self.virtual_devices > 1:
+            return self._aggregate_virtual_devices()
         cached, all_covered = self._plan()
         if cached is None:
             return 0
@@ -219,6 +263,57 @@ class BatchedFederation:
         if not all_covered:
             out.copy_(eng.params)        # rows nobody writes (dead / isolated nodes) keep their model
         return self._run_exchange(cached, out)
+
+    def _aggregate_virtual_devices(self) -> int:
+        """The exchange of a V-GPU job played on one card (see ``virtual_devices``): per virtual device one reduce
+        over its own rows + the staged rows of the others, every staged row through the (src, dst) link cipher
+        when ``encrypt`` is on."""
+        eng, V = self.engine, self.virtual_devices
+        key = self._structure_key()
+        entry = self._vd_cache.get(key)
+        if entry is None:
+            train_sets, adopt = self._round_structure()
+            blocks = partition_nodes(self.N, V)
+            vowner = np.zeros(self.N, dtype=np.int64)
+            for v, blk in enumerate(blocks):
+                vowner[list(blk)] = v
+            plans = []
+            for v in range(V):
+                ep = plan_exchange(train_sets, adopt, vowner, self.weights, v, V, blocks[v], allow_allreduce=False)
+                idx = [torch.tensor(l, dtype=torch.long, device=self.device) if l else None for l in ep.recv_lists]
+                plans.append((blocks[v], idx, build_plan(ep.groups).to(self.device), ep.n_recv))
+            covered = set(train_sets) | set(adopt)
+            entry = (plans if train_sets else None, all(i in covered for i in range(self.N)), list(self.timed_out))
+            self._vd_cache[key] = entry
+        plans, all_covered, self.timed_out = entry[0], entry[1], list(entry[2])
+        if plans is None:
+            return 0
+        out = eng.alt_slab()
+        if not all_covered:
+            out.copy_(eng.params)
+        P = eng.layout.row_stride
+        need = max(max(p[3] for p in plans), 1)
+        if self.staging is None or self.staging.shape[0] < need:
+            self.staging = torch.zeros(need, P, device=self.device)
+        moved = 0
+        for v, (blk, idx, plan, n_recv) in enumerate(plans):
+            off = 0
+            for r in range(V):
+                if idx[r] is None:
+                    continue
+                n = idx[r].numel()
+                rows = eng.params.index_select(0, idx[r])                    # what device r sends to device v
+                if self.encrypt:
+                    wire = self.comm.crypt(rows, v, decrypt=False, local=r).clone()       # on the link: ciphertext
+                    self.comm.crypt(wire, r, decrypt=True, out=self.staging[off:off + n], local=v)
+                else:
+                    self.staging[off:off + n] = rows
+                off += n
+            moved += off
+            run_plan(eng.params[blk.start:blk.stop], self.staging, out[blk.start:blk.stop], plan)
+        self.comm.bytes_sent += moved * P * 4
+        eng.swap_slabs()
+        return moved
 
     def prepare(self) -> None:
         """Ahead-of-time setup (captured graphs, exchange plan, aggregation buffers) so that the first round
@@ -245,8 +340,10 @@ class BatchedFederation:
                     cached = cached[:3] + (cached[3].to(self.device),) + cached[4:]
                 covered = set(train_sets) | set(adopt)
                 entry = (cached, all(i in covered for i in self.local))
+            entry = entry + (list(self.timed_out),)
             self._plan_cache[key] = entry
-        return entry
+        self.timed_out = list(entry[2])
+        return entry[:2]
 
     def _run_exchange(self, cached, out) -> int:
         eng = self.engine
@@ -286,7 +383,8 @@ class BatchedFederation:
         eng = self.engine
         t0 = time.perf_counter()
         phases: Dict[str, float] = {}
-        self._apply_faults()
+        enc0 = self.comm.bytes_encrypted
+        self._apply_faults("start")
 
         def tick(name, t_prev):
             if sync_timing:
@@ -310,21 +408,34 @@ class BatchedFederation:
         if pushed:
             torch.cuda.nvtx.range_pop()
         t = tick("train", t)
+        self._apply_faults("mid")             # nodes that die now have trained, but their model never arrives
+        if self.pre_aggregate_hook is not None:
+            self.pre_aggregate_hook(self)
         pushed = self._range("exchange+aggregate")
         got = self.aggregate()
         if pushed:
             torch.cuda.nvtx.range_pop()
+        if self.post_aggregate_hook is not None:
+            self.post_aggregate_hook(self)
         t = tick("aggregate", t)
         if self.federation == "SDFL":
             self._transfer_leadership()
-        # virtual heartbeats: the clock moves by the wall time of the round (at least one period)
-        self.membership.advance(max(time.perf_counter() - t0, self.membership.period))
-        self.alive = self.membership.alive().copy()
+        # Virtual heartbeats: the clock moves by the wall time of the round (at least one period) - plus
+        # AGGREGATION_TIMEOUT when some aggregator waited in vain for a member that is down but not yet evicted
+        # (aggregator.py:47-76). That wait is what lets NODE_TIMEOUT expire and the eviction happen.
+        timed_out = list(getattr(self, "timed_out", []))
+        for i in timed_out:
+            self.membership.note("aggregation_timeout", i)
+        if not self.external_clock:
+            self.membership.advance(max(time.perf_counter() - t0, self.membership.period)
+                                    + (self.aggregation_timeout if timed_out else 0.0))
+        self._sync_membership()
         n_train = eng.train_x.shape[1]
         rep = RoundReport(self.round, time.perf_counter() - t0, phases,
                           int(active.sum().item()) * n_train * self.epochs,
                           None if test is None else test["loss"], None if test is None else test["accuracy"],
-                          fit.get("Train", {}).get("loss") if fit else None, got)
+                          fit.get("Train", {}).get("loss") if fit else None, got, len(timed_out),
+                          self.comm.bytes_encrypted - enc0)
         self.reports.append(rep)
         self.round += 1
         return rep

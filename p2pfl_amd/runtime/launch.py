@@ -73,7 +73,7 @@ def load_faults(config_dir: str, parts: List[dict]) -> List[dict]:
 
 
 def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, save_models: bool = False,
-                 rounds: int = None, resume: str = None) -> dict:
+                 rounds: int = None, resume: str = None, virtual_devices: int = 1) -> dict:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -113,9 +113,13 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
                             epochs=epochs, seed=int(p0["scenario_args"].get("random_seed", 0)), rank=rank,
                             world_size=world, process_group=pg, encrypt=encrypt, scenario=scenario,
                             heartbeat_period=float(p0.get("HEARTBEAT_PERIOD", 4)),
-                            node_timeout=float(p0.get("NODE_TIMEOUT", 20)))
+                            node_timeout=float(p0.get("NODE_TIMEOUT", 20)),
+                            aggregation_timeout=float(p0.get("AGGREGATION_TIMEOUT", 60)),
+                            # the reference's failure semantics: a dead node is waited for (AGGREGATION_TIMEOUT, on
+                            # the virtual clock) until the heartbeat table evicts it NODE_TIMEOUT later
+                            instant_detection=False, virtual_devices=virtual_devices)
     for f in load_faults(config_dir, parts):
-        fed.schedule_fault(int(f["round"]), f["action"], int(f["node"]), f.get("peer"))
+        fed.schedule_fault(int(f["round"]), f["action"], int(f["node"]), f.get("peer"), f.get("phase", "start"))
     # data shards of the local nodes (real files when present, synthetic otherwise)
     shards = [build_dataset_and_model(key[0], key[1], i, n, root_dir)[0] for i in fed.local]
 
@@ -197,7 +201,8 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
         train = fed.engine.stats["Train"].summary()
         for k, i in enumerate(fed.local):
             m = {"Round": r, "Test/Loss": float(test["loss"][k]), "Train/Loss": float(train["loss"][k]),
-                 "Federation/RoundSeconds": rep.seconds, "Federation/ExchangedRows": rep.exchanged_rows}
+                 "Federation/RoundSeconds": rep.seconds, "Federation/ExchangedRows": rep.exchanged_rows,
+                 "Federation/AggregationTimeouts": rep.timeouts, "Federation/EncryptedBytes": rep.encrypted_bytes}
             for ph, sec in rep.phase_seconds.items():
                 m[f"Federation/Phase_{ph}_seconds"] = sec
             for ph, st in (("Test", test), ("Train", train)):
@@ -243,9 +248,13 @@ def main(argv=None):
     ap.add_argument("--rounds", type=int, default=None,
                     help="total rounds of the experiment (default: scenario_args.rounds); a --resume run does the remaining ones")
     ap.add_argument("--resume", default=None, help="directory with participant_<i>_final.ckpt files to start from")
+    ap.add_argument("--virtual-devices", type=int, default=1,
+                    help="one-GPU runs: split the nodes into this many virtual devices whose exchange takes the "
+                         "inter-GPU path (staging + per-link AES with --encrypt)")
     a = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO)
-    print(json.dumps(run_scenario(a.config_dir, a.device, a.encrypt, a.save_models, a.rounds, a.resume)), flush=True)
+    print(json.dumps(run_scenario(a.config_dir, a.device, a.encrypt, a.save_models, a.rounds, a.resume,
+                                  a.virtual_devices)), flush=True)
 
 
 if __name__ == "__main__":

@@ -7,9 +7,13 @@ of co-resident virtual nodes do not need hundreds of threads and sockets to agre
 this module keeps ONE table ``last_beat[node]`` on a virtual clock that the round loop advances, with the
 same two constants and the same observable behaviour:
 
-* a node that is killed / paused stops beating; it leaves every train set once ``NODE_TIMEOUT`` has passed
-  on the clock (until then its neighbours still wait for it, which in the reference ends in
-  ``AGGREGATION_TIMEOUT`` and an aggregate without it - the same result as masking it out);
+* a node that is killed / paused stops beating at once (``running()``), but its neighbours go on BELIEVING in
+  it (``believed()``) until ``NODE_TIMEOUT`` has passed on the clock without a beat: until then it stays in
+  their train sets, they wait for its model, give up after ``AGGREGATION_TIMEOUT`` and aggregate the subset
+  that did arrive (aggregator.py:47-76) - the round loop charges that wait to the clock, which is what finally
+  evicts the node (heartbeater.py:88-101) and shrinks the train sets;
+* faults land at the start of a round or in the middle of it (``phase="mid"``: the node trained, its model never
+  arrives);
 * a revived / resumed node beats again and is a member from its next beat on;
 * ``drop_link`` / ``restore_link`` remove and restore single edges of the topology (socket errors).
 
@@ -31,6 +35,7 @@ class Fault:
     action: str
     node: int
     peer: Optional[int] = None
+    phase: str = "start"          # "start": before evaluation / training; "mid": after training, before the exchange
 
 
 class VirtualMembership:
@@ -50,16 +55,20 @@ class VirtualMembership:
         self.events: List[Tuple[float, str, int]] = []        # (clock, what, node) log for observability
 
     # ------------------------------------------------------------------ faults
-    def schedule(self, round_idx: int, action: str, node: int, peer: Optional[int] = None) -> None:
+    def schedule(self, round_idx: int, action: str, node: int, peer: Optional[int] = None,
+                 phase: str = "start") -> None:
         if action not in ACTIONS:
             raise ValueError(f"unknown fault action {action!r}; known: {ACTIONS}")
         if action.endswith("link") and peer is None:
             raise ValueError(f"{action} needs a peer")
-        self.schedule_table.setdefault(int(round_idx), []).append(Fault(action, int(node), None if peer is None else int(peer)))
+        if phase not in ("start", "mid"):
+            raise ValueError(f"unknown fault phase {phase!r}")
+        self.schedule_table.setdefault(int(round_idx), []).append(
+            Fault(action, int(node), None if peer is None else int(peer), phase))
 
-    def apply_round(self, round_idx: int) -> List[Fault]:
-        """Apply the faults scheduled for ``round_idx`` (called at the start of a round)."""
-        done = self.schedule_table.get(round_idx, [])
+    def apply_round(self, round_idx: int, phase: Optional[str] = "start") -> List[Fault]:
+        """Apply the faults scheduled for ``round_idx`` and ``phase`` (None: every phase - replaying a finished round)."""
+        done = [f for f in self.schedule_table.get(round_idx, []) if phase is None or f.phase == phase]
         for f in done:
             if f.action in ("kill", "pause"):
                 self.beating[f.node] = False
@@ -90,9 +99,21 @@ class VirtualMembership:
             self.events.append((self.clock, "evicted", int(i)))
         return [int(i) for i in evicted]
 
+    def note(self, what: str, node: int) -> None:
+        """Log an observation of the round loop (e.g. ``aggregation_timeout``) on the membership clock."""
+        self.events.append((self.clock, what, int(node)))
+
     # ------------------------------------------------------------------ views
+    def running(self) -> np.ndarray:
+        """Nodes whose own process is up (they evaluate, train, contribute)."""
+        return self.beating
+
+    def believed(self) -> np.ndarray:
+        """Nodes the rest of the network still counts as members (train-set membership)."""
+        return self.member
+
     def alive(self) -> np.ndarray:
-        """Nodes that take part in rounds: beating AND still believed alive by the others."""
+        """Nodes that are up AND counted in: beating and believed."""
         return self.member & self.beating
 
     def get_nodes(self) -> List[int]:

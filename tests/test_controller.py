@@ -98,7 +98,7 @@ def test_batched_launcher_faults_checkpoints_and_resume(tmp_path):
     json.dump([{"round": 1, "action": "kill", "node": 3}, {"round": 2, "action": "revive", "node": 3}],
               open(os.path.join(cdir, "faults.json"), "w"))
     s1 = run_scenario(cdir, device="cpu", save_models=True)
-    assert s1["rounds"] == 2 and s1["first_round"] == 0 and [e[1:] for e in s1["membership_events"]] == [["kill", 3]]
+    assert s1["rounds"] == 2 and s1["first_round"] == 0 and [e[1] for e in s1["membership_events"]] == ["kill", "aggregation_timeout", "aggregation_timeout", "evicted"]
     log3 = open(tmp_path / "logs" / "scen" / "participant_3.log").read()
     assert "round 0 role aggregator alive True" in log3 and "round 1 role aggregator alive False" in log3
     rows = open(tmp_path / "logs" / "scen" / "metrics" / "participant_0" / "metrics.csv").read()
@@ -109,7 +109,7 @@ def test_batched_launcher_faults_checkpoints_and_resume(tmp_path):
     # the kill of round 1 is replayed without training, the revival of round 2 happens in the resumed round
     s2 = run_scenario(cdir, device="cpu", rounds=3, resume=str(tmp_path / "logs" / "scen"))
     assert s2["first_round"] == 2 and s2["rounds"] == 1
-    assert [e[1:] for e in s2["membership_events"]] == [["kill", 3], ["revive", 3]]
+    assert [e[1:] for e in s2["membership_events"] if e[1] in ("kill", "revive")] == [["kill", 3], ["revive", 3]]
     assert "round 2 role aggregator alive True" in open(tmp_path / "logs" / "scen" / "participant_3.log").read()
     # resumed from trained weights: the very first evaluation is already good
     first_eval = [l for l in open(tmp_path / "logs" / "scen" / "participant_1.log").read().splitlines() if "round 2 " in l][0]

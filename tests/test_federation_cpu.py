@@ -204,3 +204,73 @@ def test_two_rank_exchange_matches_single_rank(kind, encrypt):
     mp.spawn(_worker, args=(2, _free_port(), kind, encrypt, out), nprocs=2, join=True)
     got = torch.cat([out[0], out[1]], dim=0)
     assert torch.allclose(got, ref.engine.params[:, :8], atol=1e-6)
+
+
+# ------------------------------------------------------------------ churn with the reference's failure semantics
+def make_churn_fed(kind, n, **kw):
+    fed = BatchedFederation(SPEC, topo(kind, n), device="cpu", engine="eager", epochs=1, seed=5,
+                            instant_detection=False, node_timeout=20.0, aggregation_timeout=60.0, **kw)
+    fed.init_params()
+    fed.set_local_data(*synthetic_shards(n, 32, 8, 16, 10, seed=1))
+    perturb(fed)
+    return fed
+
+
+def test_killed_node_costs_one_aggregation_timeout_then_is_evicted():
+    """heartbeater.py:88-101 + aggregator.py:47-76: a node that dies keeps its place in its neighbours' train sets
+    until NODE_TIMEOUT passes; meanwhile they wait AGGREGATION_TIMEOUT and aggregate the subset that arrived."""
+    fed = make_churn_fed("ring", 6)                       # ring 0-1-2-3-4-5-0
+    base = fed.engine.params[0, 0].item()
+    fed.schedule_fault(1, "kill", 2)
+    r0 = fed.run_round(evaluate=False)
+    assert r0.timeouts == 0 and fed.believed.all()
+    after0 = fed.engine.params[:, 0].clone()
+    r1 = fed.run_round(evaluate=False)
+    # round 1: node 2 is down but still EXPECTED by 1 and 3 -> both time out and average who is left
+    assert r1.timeouts == 2 and sorted(fed.timed_out) == [1, 3]
+    ev = [(what, node) for _, what, node in fed.membership.events]
+    assert ev == [("kill", 2), ("aggregation_timeout", 1), ("aggregation_timeout", 3), ("evicted", 2)]
+    # the 60 s wait is on the virtual clock and is what expired NODE_TIMEOUT
+    assert fed.membership.clock >= 60.0 and not fed.believed[2] and not fed.alive[2]
+    trained = after0 + torch.tensor([(g + 1) / 100.0 for g in range(6)])
+    assert abs(fed.engine.params[1, 0].item() - (trained[0] + trained[1]).item() / 2) < 1e-6      # {0, 1}, without 2
+    assert abs(fed.engine.params[3, 0].item() - (trained[3] + trained[4]).item() / 2) < 1e-6      # {3, 4}, without 2
+    assert abs(fed.engine.params[2, 0].item() - after0[2].item()) < 1e-7                          # dead: untouched
+    # round 2: 2 is evicted, the train sets shrank, nobody waits any more
+    r2 = fed.run_round(evaluate=False)
+    assert r2.timeouts == 0 and fed.train_set(1) == [0, 1] and fed.train_set(3) == [3, 4]
+    assert base == base
+
+
+def test_mid_round_death_trains_but_never_delivers():
+    fed = make_churn_fed("ring", 5)
+    fed.schedule_fault(0, "kill", 4, phase="mid")
+    before = fed.engine.params[:, 0].clone()
+    rep = fed.run_round(evaluate=False)
+    trained = before + torch.tensor([(g + 1) / 100.0 for g in range(5)])
+    assert rep.train_samples == 5 * 32                   # node 4 did train this round ...
+    assert rep.timeouts == 2 and sorted(fed.timed_out) == [0, 3]      # ... but its neighbours waited in vain
+    assert abs(fed.engine.params[0, 0].item() - (trained[0] + trained[1]).item() / 2) < 1e-6
+    assert abs(fed.engine.params[4, 0].item() - trained[4].item()) < 1e-6         # its own row: trained, not aggregated
+    rep = fed.run_round(evaluate=False)
+    assert rep.train_samples == 4 * 32 and rep.timeouts == 0         # evicted by the timeout round's clock
+
+
+@pytest.mark.parametrize("kind,encrypt", [("random", True), ("ring", False), ("fully", True)])
+def test_virtual_devices_take_the_inter_gpu_path_on_one_device(kind, encrypt):
+    """virtual_devices=V: rows crossing from one virtual device to another go gather -> link cipher -> staging ->
+    decrypt -> reduce; the result must equal the plain single-shard aggregation."""
+    ref = make_fed(kind, 7)
+    perturb(ref)
+    fed = BatchedFederation(SPEC, topo(kind, 7), device="cpu", engine="eager", epochs=1, seed=5, encrypt=encrypt,
+                            virtual_devices=3)
+    fed.init_params()
+    fed.set_local_data(*synthetic_shards(7, 32, 8, 16, 10, seed=1))
+    perturb(fed)
+    for _ in range(2):
+        ref.run_round(evaluate=False)
+        rep = fed.run_round(evaluate=False)
+    assert torch.allclose(fed.engine.params, ref.engine.params, atol=1e-6)
+    assert rep.exchanged_rows > 0
+    assert (rep.encrypted_bytes == 2 * rep.exchanged_rows * fed.engine.layout.row_stride * 4) if encrypt \
+        else rep.encrypted_bytes == 0

@@ -185,9 +185,19 @@ class Controller:
 
     @staticmethod
     def remove_files_by_scenario(scenario_name):
+        """Delete ``<config_dir>/<scenario>`` and ``<log_dir>/<scenario>`` - and nothing else: the name must be one
+        plain path component (never "." / ".." / a path) and the target must resolve to a strict descendant of
+        its root."""
+        name = str(scenario_name or "")
+        if not name or set(name) <= {"."} or name != os.path.basename(name) or os.sep in name or "/" in name:
+            raise ValueError(f"refusing to remove scenario {scenario_name!r}")
         for root in (os.environ.get("FEDSTELLAR_CONFIG_DIR"), os.environ.get("FEDSTELLAR_LOGS_DIR")):
-            if root and scenario_name:
-                shutil.rmtree(os.path.join(root, scenario_name), ignore_errors=True)
+            if not root:
+                continue
+            real_root, target = os.path.realpath(root), os.path.realpath(os.path.join(root, name))
+            if target == real_root or os.path.commonpath([real_root, target]) != real_root:
+                raise ValueError(f"refusing to remove {target!r}: outside {real_root!r}")
+            shutil.rmtree(target, ignore_errors=True)
 
     # ------------------------------------------------------------------ scenario generation
     @staticmethod
@@ -241,11 +251,17 @@ class Controller:
         self.n_nodes = len(participant_files)
         self.topologymanager = self.create_topology(matrix=self.matrix) if self.matrix is not None else self.create_topology()
 
+        # token the nodes present to the controller's ingest routes (status / log push carry no login session)
+        import secrets
+        token = secrets.token_hex(16)
+        with open(os.path.join(self.config_dir, ".token"), "w") as f:
+            f.write(token)
         is_start_node, idx_start_node = False, 0
         for i in range(self.n_nodes):
             path = os.path.join(self.config_dir, f"participant_{i}.json")
             with open(path) as f:
                 pc = json.load(f)
+            pc["scenario_args"]["controller_token"] = token
             pc["scenario_args"]["federation"] = self.federation
             pc["scenario_args"]["n_nodes"] = self.n_nodes
             pc["scenario_args"]["simulation"] = bool(self.simulation)

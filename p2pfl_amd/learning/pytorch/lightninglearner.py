@@ -146,19 +146,29 @@ class LightningLearner(NodeLearner):
         if self._engine is None:
             from ...runtime.engine import HipEngine
             bs = getattr(self.data, "batch_size", 32)
-            eng = HipEngine(self.model.spec, 1, self.device, batch_size=bs)
+            eng = HipEngine(self.model.spec, 1, self.device, batch_size=bs, log_steps=True)
             un = lambda t: None if t is None else t.unsqueeze(0)
             eng.set_data(*(un(t) for t in self.data.tensors()))
+            # The model's parameters BECOME views of slab row 0 (device-side pack once, then aliasing): what the
+            # kernels train is what state_dict() / load_state_dict() see, with no copy at all per fit / evaluate -
+            # the reference's D2H + pickle site (lightninglearner.py:73-89) is only touched when a payload is
+            # really encoded for the wire.
+            self.model.to(self.device)
+            eng.layout.state_dict_to_row(self.model.state_dict(), eng.params[0])
+            for name, p in self.model.named_parameters():
+                p.data = eng.layout.view(eng.params, name)[0]
             self._engine = eng
         return self._engine
 
     def _model_to_engine(self, eng):
-        eng.layout.state_dict_to_row(self.model.state_dict(), eng.params[0])
+        """No-op when the parameters alias the slab row (always, unless someone re-assigned ``p.data``)."""
+        for name, p in self.model.named_parameters():
+            if p.data_ptr() != eng.layout.view(eng.params, name)[0].data_ptr():
+                eng.layout.view(eng.params, name)[0].copy_(p.data.to(eng.params.device))
+                p.data = eng.layout.view(eng.params, name)[0]
 
     def _engine_to_model(self, eng):
-        sd = eng.layout.row_to_state_dict(eng.params[0])
-        own = self.model.state_dict()
-        self.model.load_state_dict(OrderedDict((k, sd[k].to(own[k].device)) for k in own))
+        pass            # the model's parameters are views of the row the engine just trained
 
     # ------------------------------------------------------------------ logging helpers
     def _log(self, metrics, step=None):
@@ -223,6 +233,10 @@ class LightningLearner(NodeLearner):
                     self._engine_to_model(eng)
                     eng.synchronize()
                 self._local_step = eng.steps_per_epoch() * self.epochs
+                per_step = eng.step_losses()
+                if per_step is not None:            # Train/Loss every 20 steps (lightninglearner.py:188)
+                    for t in range(19, per_step.shape[0], 20):
+                        self._log({"Train/Loss": float(per_step[t, 0])}, step=t + 1)
                 self._log_phase("Train", out["Train"]["loss"][0], out["Train"]["confusion"][0], self._local_step)
                 if "Validation" in out:
                     self._log_phase("Validation", out["Validation"]["loss"][0], out["Validation"]["confusion"][0],

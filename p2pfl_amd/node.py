@@ -561,7 +561,8 @@ class Node(BaseNode):
         try:
             import requests
             r = requests.post(url, data=json.dumps(self.config.participant),
-                              headers={"Content-Type": "application/json"}, timeout=2)
+                              headers={"Content-Type": "application/json",
+                                       "X-Scenario-Token": str(sa.get("controller_token") or "")}, timeout=2)
             if r.status_code != 200:
                 logging.debug("Error received from controller: %s", r.status_code)
         except Exception:

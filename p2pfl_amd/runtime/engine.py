@@ -119,6 +119,11 @@ class ShardEngine:
                 return None, None
             x = x.reshape(self.K, x.shape[1], -1).to(self.device, torch.float32).contiguous()
             y = y.to(self.device, torch.int32).contiguous()
+            # the loss kernel indexes logits and the confusion matrix with the label: an out-of-range one (a foreign
+            # FEMNIST / SYSCALL file) must fail here, like torch's CrossEntropyLoss does, not corrupt device memory
+            if y.numel() and (int(y.min()) < 0 or int(y.max()) >= self.spec.num_classes):
+                raise ValueError(f"labels must lie in [0, {self.spec.num_classes}): got "
+                                 f"[{int(y.min())}, {int(y.max())}]")
             return x, y
         self.train_x, self.train_y = put(train_x, train_y)
         self.val_x, self.val_y = put(val_x, val_y)
@@ -269,8 +274,13 @@ class HipEngine(ShardEngine):
     """Client-batched gfx950 kernels + hipGraph replay (see module docstring)."""
 
     def __init__(self, *a, use_graph: bool = True, fuse_optimizer: bool = True, overlap: bool = True,
-                 precision: Optional[str] = None, **kw):
+                 precision: Optional[str] = None, log_steps: bool = False, **kw):
         super().__init__(*a, **kw)
+        # log_steps: keep the running (loss sum, sample count) of every optimizer step in a device table written
+        # from inside the captured graph, so per-step Train/Loss can be reported like the reference's
+        # log_every_n_steps=20 (lightninglearner.py:188) without leaving the graph
+        self.log_steps = bool(log_steps)
+        self._step_log = None
         if self.device.type != "cuda":
             raise RuntimeError("HipEngine needs a GPU device")
         from ..ops import hip
@@ -436,6 +446,31 @@ class HipEngine(ShardEngine):
         st = self.stats[phase]
         hip.softmax_ce(x, labels, sidx, self.dact[-1] if train else None, st.loss_sum, st.correct, st.count,
                        st.confusion, n_valid)
+        if train:
+            self._record_step()
+
+    def _record_step(self) -> None:
+        if self._step_log is not None and self._step_pos < self._step_log.shape[0]:
+            st = self.stats["Train"]
+            self._step_log[self._step_pos, 0].copy_(st.loss_sum)
+            self._step_log[self._step_pos, 1].copy_(st.count)
+            self._step_pos += 1
+
+    def step_losses(self) -> Optional[torch.Tensor]:
+        """[steps, K] mean training loss of every optimizer step of the last ``fit`` (needs ``log_steps``)."""
+        if self._step_log is None:
+            return None
+        log = self._step_log.cpu()
+        prev = torch.zeros_like(log[0])
+        out = []
+        for t in range(log.shape[0]):
+            cur = log[t]
+            if (cur[1] < prev[1]).any():          # the per-epoch statistics were reset before this step
+                prev = torch.zeros_like(prev)
+            d = cur - prev
+            out.append(d[0] / d[1].clamp(min=1))
+            prev = cur
+        return torch.stack(out)
 
     def _backward(self, data, sidx, step_index: int = 1) -> None:
         hip, layers = self.hip, self.spec.layers
@@ -596,6 +631,7 @@ class HipEngine(ShardEngine):
             x = self.act[i]
         st = self.stats["Train"]
         hip.softmax_ce(x, labels, sidx, self.dact[-1], st.loss_sum, st.correct, st.count, st.confusion, n_valid)
+        self._record_step()
         for i in range(len(layers) - 1, nc - 1, -1):
             l = layers[i]
             W, _ = self._w(self.params, l)
@@ -648,6 +684,7 @@ class HipEngine(ShardEngine):
                 self._eval_pass(self.val_x, self.val_y, "Validation")
 
     def _train(self, epochs: int, steps: int, n: int) -> None:
+        self._step_pos = 0
         # The two-stream schedule only ever exists as branches of a captured graph. Launched eagerly (as the
         # warm-up before a capture used to do, or with use_graph=False) the same stream / event pattern
         # stalled on the device now and then - always in the first fit of an engine in a long-lived process,
@@ -679,6 +716,9 @@ class HipEngine(ShardEngine):
                 self._bc_buf = torch.zeros(bc.shape, device=self.device)
                 self._graphs.clear()
             self._bc_buf.copy_(bc, non_blocking=True)
+        if self.log_steps and (self._step_log is None or self._step_log.shape[0] != total):
+            self._step_log = torch.zeros(total, 2, self.K, device=self.device)
+            self._graphs.clear()
         saved = None
         if active is not None and not bool(torch.as_tensor(active).all()):
             inactive = (~torch.as_tensor(active, dtype=torch.bool)).nonzero().flatten().to(self.device)

@@ -185,7 +185,8 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
             cfgp = dict(parts[i])
             cfgp["device_args"] = dict(cfgp["device_args"], role=fed.roles[i])
             requests.post(f"http://{ctrl}/scenario/{scenario}/node/update", data=json.dumps(cfgp),
-                          headers={"Content-Type": "application/json"}, timeout=1)
+                          headers={"Content-Type": "application/json", "X-Scenario-Token":
+                                   str(parts[i]["scenario_args"].get("controller_token") or "")}, timeout=1)
         except Exception:
             pass
 

@@ -81,6 +81,15 @@ class ParamLayout:
         return OrderedDict((s.name, row[s.offset:s.offset + s.numel].reshape(s.shape).clone()) for s in self.slots)
 
     def state_dict_to_row(self, sd, row: torch.Tensor) -> None:
+        """Pack a state_dict into a slab row. Tensors that already live on the row's device are copied there
+        directly (device-side pack: no host hop, no numpy); anything else goes through the host path."""
+        if all(isinstance(sd[s.name], torch.Tensor) and sd[s.name].device == row.device for s in self.slots):
+            for s in self.slots:
+                t = sd[s.name].detach()
+                if tuple(t.shape) != s.shape:
+                    raise ValueError(f"{s.name}: expected shape {s.shape}, got {tuple(t.shape)}")
+                row[s.offset:s.offset + s.numel].copy_(t.reshape(-1))
+            return
         self.arrays_to_row([sd[s.name].detach().cpu().numpy() for s in self.slots], row)
 
     def check_state_dict(self, sd) -> bool:

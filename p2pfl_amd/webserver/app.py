@@ -43,9 +43,34 @@ _SAFE = re.compile(r"^[A-Za-z0-9_.\-]+$")
 
 
 def _safe(name):
-    if not name or not _SAFE.match(name):
+    """A single path component: letters, digits, ``_ . -`` - and never a name made of dots only ("." / ".." would
+    address the config / log directory itself or its parent)."""
+    if not name or not _SAFE.match(name) or set(name) <= {"."}:
         abort(400)
     return name
+
+
+def _under(root, *parts):
+    """``root/parts...`` with every part checked and the result verified to stay inside ``root`` (symlinks resolved)."""
+    path = os.path.join(root, *[_safe(str(p)) for p in parts])
+    real_root = os.path.realpath(root)
+    if os.path.commonpath([real_root, os.path.realpath(path)]) != real_root or os.path.realpath(path) == real_root:
+        abort(400)
+    return path
+
+
+def _ingest_allowed(scenario_name):
+    """Node-ingest routes carry no session: they are authenticated by the scenario's token, which the controller
+    writes into ``<config_dir>/<scenario>/.token`` and into every participant config
+    (``scenario_args.controller_token``); nodes send it back as ``X-Scenario-Token``."""
+    tok_path = os.path.join(_under(app.config["config_dir"], scenario_name), ".token")
+    if not os.path.exists(tok_path):
+        return False
+    with open(tok_path) as f:
+        want = f.read().strip()
+    got = request.headers.get("X-Scenario-Token", "")
+    import hmac
+    return bool(want) and hmac.compare_digest(want, got)
 
 
 def _dirs():
@@ -261,12 +286,13 @@ def update_topology(scenario_name, nodes):
 @app.route("/scenario/<scenario_name>/node/update", methods=["POST"])
 def fedstellar_update_node(scenario_name):
     """Status ingest from the nodes: the body is the node's live participant config."""
-    _safe(scenario_name)
+    cdir = _under(app.config["config_dir"], scenario_name)
+    if not _ingest_allowed(scenario_name):
+        return abort(403)
     cfg = request.get_json(force=True, silent=True)
     if not cfg or "device_args" not in cfg or "network_args" not in cfg:
         return abort(400)
     ts = datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S.%f")
-    cdir = os.path.join(app.config["config_dir"], scenario_name)
     if os.path.isdir(cdir):
         with open(os.path.join(cdir, f"participant_{int(cfg['device_args']['idx'])}.json"), "w") as f:
             json.dump(cfg, f, sort_keys=False, indent=2)
@@ -296,11 +322,10 @@ def fedstellar_monitoring_log(scenario_name, idx, kind):
     (reference app.py:443-453,479-500)."""
     if "user" not in session:
         return abort(401)
-    _safe(scenario_name)
     suffix = _LOG_SUFFIX.get(kind)
     if suffix is None:
         return abort(404)
-    path = os.path.join(app.config["log_dir"], scenario_name, f"participant_{idx}{suffix}")
+    path = os.path.join(_under(app.config["log_dir"], scenario_name), f"participant_{idx}{suffix}")
     if not os.path.exists(path):
         return abort(404)
     return send_file(path, mimetype="text/plain", as_attachment=True)
@@ -312,7 +337,7 @@ def fedstellar_monitoring_log_x(scenario_name, idx, number):
     the monitoring page, reference app.py:455-476)."""
     if "user" not in session:
         return abort(401)
-    text = _tail(os.path.join(app.config["log_dir"], _safe(scenario_name), f"participant_{idx}.log"),
+    text = _tail(os.path.join(_under(app.config["log_dir"], scenario_name), f"participant_{idx}.log"),
                  max(1, min(int(number), 10000)))
     return app.response_class("No logs available" if text is None else text, mimetype="text/plain")
 
@@ -321,8 +346,10 @@ def fedstellar_monitoring_log_x(scenario_name, idx, number):
 def fedstellar_update_node_logs(scenario_name, uid):
     """Log push from a node that cannot share the log directory (commented out in the reference,
     app.py:407-416): the body is appended to ``<log_dir>/<scenario>/remote_<uid>.log``."""
-    _safe(scenario_name), _safe(uid)
-    d = os.path.join(app.config["log_dir"], scenario_name)
+    _safe(uid)
+    d = _under(app.config["log_dir"], scenario_name)
+    if not _ingest_allowed(scenario_name):
+        return abort(403)
     os.makedirs(d, exist_ok=True)
     with open(os.path.join(d, f"remote_{uid}.log"), "a") as f:
         f.write(request.get_data(as_text=True)[:1 << 20])
@@ -352,7 +379,7 @@ def fedstellar_logs_erase():
 
 @app.route("/scenario/<scenario_name>/topology/image/")
 def fedstellar_monitoring_image(scenario_name):
-    path = os.path.join(app.config["log_dir"], _safe(scenario_name), "topology.png")
+    path = os.path.join(_under(app.config["log_dir"], scenario_name), "topology.png")
     return send_file(path, mimetype="image/png") if os.path.exists(path) else abort(404)
 
 
@@ -384,7 +411,7 @@ def fedstellar_stop_scenario(scenario_name):
 def fedstellar_remove_scenario(scenario_name):
     if "user" not in session:
         return abort(401)
-    _safe(scenario_name)
+    _under(app.config["config_dir"], scenario_name), _under(app.config["log_dir"], scenario_name)
     stop_scenario(scenario_name)
     db.remove_nodes_by_scenario_name(scenario_name)
     db.remove_scenario_by_name(scenario_name)
@@ -434,7 +461,7 @@ def fedstellar_api_statistics(scenario_name):
 def fedstellar_statistics_download(scenario_name):
     if "user" not in session:
         return abort(401)
-    root = os.path.join(app.config["log_dir"], _safe(scenario_name), "metrics")
+    root = os.path.join(_under(app.config["log_dir"], scenario_name), "metrics")
     if not os.path.isdir(root):
         return abort(404)
     mem = io.BytesIO()

@@ -274,3 +274,19 @@ def test_virtual_devices_take_the_inter_gpu_path_on_one_device(kind, encrypt):
     assert rep.exchanged_rows > 0
     assert (rep.encrypted_bytes == 2 * rep.exchanged_rows * fed.engine.layout.row_stride * 4) if encrypt \
         else rep.encrypted_bytes == 0
+
+
+def test_out_of_range_labels_are_refused():
+    """loss.hip indexes logits / the confusion matrix with the label: a foreign data file with a label outside
+    [0, C) must raise like torch's CrossEntropyLoss, on every engine."""
+    from p2pfl_amd.runtime.engine import EagerEngine
+    eng = EagerEngine(SPEC, 2, "cpu")
+    tx, ty, vx, vy, ex, ey = synthetic_shards(2, 16, 4, 8, 10, seed=1)
+    bad = ty.clone()
+    bad[1, 3] = 10
+    with pytest.raises(ValueError, match="labels must lie in"):
+        eng.set_data(tx, bad, vx, vy, ex, ey)
+    bad[1, 3] = -1
+    with pytest.raises(ValueError):
+        eng.set_data(tx, bad, vx, vy, ex, ey)
+    eng.set_data(tx, ty, vx, vy, ex, ey)

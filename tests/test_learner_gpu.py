@@ -58,3 +58,32 @@ def test_two_engine_learners_in_threads_share_the_gpu():
     for ln, r in zip(lns, ref):
         loss = ln.evaluate()[0]
         assert loss == loss and loss < r * 1.5
+
+
+def test_engine_learner_aliases_the_slab_and_logs_every_20_steps():
+    """K=1 learner hygiene: the model's parameters are views of slab row 0 (no host hop per fit / evaluate) and
+    Train/Loss is reported every 20 optimizer steps from a table the captured graph fills."""
+    class Rec:
+        def __init__(self):
+            self.rows, self.global_step = [], 0
+        def log_metrics(self, metrics, step=None):
+            self.rows.append((step, dict(metrics)))
+    ln = _learner("MNIST", "MLP", n=50)          # 1200 rows -> 1080 train -> 34 steps per epoch
+    ln.logger = Rec()
+    ln.set_epochs(2)
+    ln.init()
+    ln.fit()
+    eng = ln._engine
+    for name, p in ln.model.named_parameters():
+        assert p.is_cuda and p.data_ptr() == eng.layout.view(eng.params, name)[0].data_ptr()
+    steps = [s for s, m in ln.logger.rows if set(m) == {"Train/Loss"}]
+    assert steps == [20, 40, 60]
+    losses = [m["Train/Loss"] for s, m in ln.logger.rows if set(m) == {"Train/Loss"}]
+    assert all(0 < l < 5 for l in losses) and losses[-1] < losses[0]
+    # a payload from the wire (host tensors) lands in the slab row through load_state_dict, aliasing intact
+    sd = {k: torch.full_like(v, 0.25).cpu() for k, v in ln.get_parameters().items()}
+    ln.set_parameters(sd)
+    assert torch.all(eng.params[0, :100] == 0.25)
+    ln.evaluate()
+    for name, p in ln.model.named_parameters():
+        assert p.data_ptr() == eng.layout.view(eng.params, name)[0].data_ptr()

@@ -80,12 +80,26 @@ def test_node_update_and_monitoring_online_rule(web):
     name = "fedstellar_DFL_test"
     appmod.db.scenario_update_record(name, "now", "", "t", "d", "running", "")
     os.makedirs(tmp / "config" / name)
+    # the ingest routes carry no session: without the scenario's token (controller -> .token + participant configs,
+    # node -> X-Scenario-Token) nothing is written
+    body = json.dumps(_participant(0, name, 46000))
+    assert c.post(f"/scenario/{name}/node/update", data=body, content_type="application/json").status_code == 403
+    (tmp / "config" / name / ".token").write_text("s3cret")
+    assert c.post(f"/scenario/{name}/node/update", data=body, content_type="application/json",
+                  headers={"X-Scenario-Token": "wrong"}).status_code == 403
+    assert not (tmp / "config" / name / "participant_0.json").exists()
+    tok = {"X-Scenario-Token": "s3cret"}
     for i in range(2):
         r = c.post(f"/scenario/{name}/node/update", data=json.dumps(_participant(i, name, 46000 + i)),
-                   content_type="application/json")
+                   content_type="application/json", headers=tok)
         assert r.status_code == 200 and r.get_json()["node_uid"] == f"uid{i}"
     assert (tmp / "config" / name / "participant_1.json").exists()
-    assert c.post(f"/scenario/{name}/node/update", data="{}", content_type="application/json").status_code == 400
+    assert c.post(f"/scenario/{name}/node/update", data="{}", content_type="application/json", headers=tok).status_code == 400
+    # names made of dots address the config directory itself / its parent: refused on every route
+    for bad in (".", "..", "%2e", "%2e%2e"):
+        assert c.post(f"/scenario/{bad}/node/update", data=body, content_type="application/json", headers=tok).status_code \
+            in (400, 404, 308)
+        assert c.post(f"/scenario/{bad}/node/x/update/logs", data="x", headers=tok).status_code in (400, 404, 308)
     d = c.get(f"/api/scenario/{name}/monitoring").get_json()
     assert d["scenario_status"] == "running" and [n["status"] for n in d["nodes_table"]] == [True, True]
     assert d["nodes_table"][0]["neighbors"] == "127.0.0.1:46001"
@@ -128,7 +142,11 @@ def test_logs_statistics_and_download(web):
     assert c.get(f"/scenario/{name}/node/0/errorlog").status_code == 404
     assert c.get(f"/scenario/{name}/node/0/other").status_code == 404
     # log push from a remote node + controller log view / erase
-    assert c.post(f"/scenario/{name}/node/abc123/update/logs", data="remote line\n").status_code == 200
+    assert c.post(f"/scenario/{name}/node/abc123/update/logs", data="remote line\n").status_code == 403
+    os.makedirs(tmp / "config" / name, exist_ok=True)
+    (tmp / "config" / name / ".token").write_text("tok")
+    assert c.post(f"/scenario/{name}/node/abc123/update/logs", data="remote line\n",
+                  headers={"X-Scenario-Token": "tok"}).status_code == 200
     assert (ldir / "remote_abc123.log").read_text() == "remote line\n"
     assert c.get("/logs").status_code == 404
     (tmp / "logs" / "server.log").write_text("controller says hi\n")
@@ -219,3 +237,22 @@ def test_pages_render_with_bundled_scripts(web):
     d = c.get(f"/api/scenario/{name}/monitoring").get_json()
     assert d["nodes_table"][0]["latitude"] == "40.4"
     assert b"lineChart" in c.get(f"/scenario/{name}/statistics/").data
+
+
+def test_remove_refuses_dot_names_and_keeps_the_roots(web):
+    """/scenario/%2e/remove used to rmtree the whole config and log directories (".." their parents)."""
+    appmod, c, tmp = web
+    from p2pfl_amd.controller import Controller
+    (tmp / "config" / "keep").mkdir(parents=True, exist_ok=True)
+    (tmp / "logs" / "keep").mkdir(parents=True, exist_ok=True)
+    _login(c)
+    for bad in (".", "..", "%2e", "%2e%2e", "..%2f..", "a%2f..%2f.."):
+        assert c.get(f"/scenario/{bad}/remove").status_code in (400, 404, 308)
+    assert (tmp / "config" / "keep").is_dir() and (tmp / "logs" / "keep").is_dir()
+    os.environ["FEDSTELLAR_CONFIG_DIR"], os.environ["FEDSTELLAR_LOGS_DIR"] = str(tmp / "config"), str(tmp / "logs")
+    for bad in (".", "..", "", "a/..", "../x"):
+        with pytest.raises(ValueError):
+            Controller.remove_files_by_scenario(bad)
+    assert (tmp / "config" / "keep").is_dir() and (tmp / "logs" / "keep").is_dir()
+    Controller.remove_files_by_scenario("keep")
+    assert not (tmp / "config" / "keep").exists() and (tmp / "config").is_dir()

@@ -33,11 +33,9 @@ from ..learner import NodeLearner
 from ..metrics import metrics_from_confusion
 
 
-# Several nodes in ONE process (tests, examples/single_device.py) each own a one-client HipEngine. Their rounds are
-# captured hipGraphs with a parallel branch; two of them in flight from different threads stalled on the device
-# (inside a long test process, now and then), so engine calls of one process take turns - the GPU would run them one
-# after the other anyway. Production layouts are one process per node, or all nodes in one BatchedFederation.
-_ENGINE_LOCK = threading.Lock()
+# Several nodes in ONE process (tests, examples/single_device.py) each own a one-client HipEngine and may fit from
+# different threads at once: that needs no lock - the stall that once made engine calls take turns was the
+# high-priority side stream (runtime/engine.py, HipEngine.__init__; tools/diag_stall.py).
 
 
 def resolve_device(config) -> torch.device:
@@ -226,12 +224,11 @@ class LightningLearner(NodeLearner):
             self.create_trainer()
             self._local_step = 0
             if self._use_engine():
-                with _ENGINE_LOCK:
-                    eng = self._get_engine()
-                    self._model_to_engine(eng)
-                    out = eng.fit(self.epochs)
-                    self._engine_to_model(eng)
-                    eng.synchronize()
+                eng = self._get_engine()
+                self._model_to_engine(eng)
+                out = eng.fit(self.epochs)
+                self._engine_to_model(eng)
+                eng.synchronize()
                 self._local_step = eng.steps_per_epoch() * self.epochs
                 per_step = eng.step_losses()
                 if per_step is not None:            # Train/Loss every 20 steps (lightninglearner.py:188)
@@ -262,11 +259,10 @@ class LightningLearner(NodeLearner):
             if self.epochs <= 0:
                 return None
             if self._use_engine():
-                with _ENGINE_LOCK:
-                    eng = self._get_engine()
-                    self._model_to_engine(eng)
-                    out = eng.evaluate()
-                    eng.synchronize()
+                eng = self._get_engine()
+                self._model_to_engine(eng)
+                out = eng.evaluate()
+                eng.synchronize()
                 loss, cm = float(out["loss"][0]), out["confusion"][0]
             else:
                 self.model.to(self.device)

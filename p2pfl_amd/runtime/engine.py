@@ -258,6 +258,18 @@ class EagerEngine(ShardEngine):
 # ======================================================================================
 # HIP engine
 # ======================================================================================
+def pending_stream_events():
+    """(engine id, event name) of the first unsignalled debug events of every live engine (P2PFL_STREAM_DEBUG=1)."""
+    import gc
+    out = []
+    for obj in gc.get_objects():
+        if isinstance(obj, HipEngine) and obj._stream_debug:
+            names = [(n, ev.query()) for n, ev in obj._stream_debug]
+            done = sum(1 for _, q in names if q)
+            out.append((id(obj), done, len(names), [n for n, q in names if not q][:4]))
+    return out
+
+
 def live_aux_streams():
     """(role, stream) of every auxiliary HIP stream of the engines alive in this process - for the stall
     diagnostics (tests/conftest.py, tools/diag_streams.py). Found through the garbage collector on demand: a
@@ -339,6 +351,7 @@ class HipEngine(ShardEngine):
             self._adam_ranges = ranges
         self._graphs: Dict[tuple, tuple] = {}
         self._capturing = False
+        self._stream_debug = [] if os.environ.get("P2PFL_STREAM_DEBUG") else None
         self._perm_buf = None
         self._bc_buf = None
         self._eval_graph = None
@@ -353,11 +366,19 @@ class HipEngine(ShardEngine):
         self.overlap = (bool(overlap) and self.nc > 0 and self.nc in self._fused
                         and L.by_name[first_dense.weight].numel >= (1 << 20))
         if self.overlap:
-            self._side = torch.cuda.Stream(device=dev, priority=int(os.environ.get('P2PFL_SIDE_PRIO', '-1')))
+            # SAME priority as the launch stream, on purpose. Root cause of the round-1 "eager two-stream stall"
+            # (tools/diag_stall.py, docs/kernels.rst): with a HIGH-priority side stream (priority -1) the join
+            # `main.wait_stream(side)` - a normal-priority stream waiting for an event of a high-priority one - never
+            # resolves on the 4th high-priority stream a process creates (2nd engine of the 2nd batch of engines;
+            # deterministic on ROCm 7.2, GPU_MAX_HW_QUEUES 4 or 8 alike): side's event IS signalled, main's
+            # barrier on it is not released, both streams stay BUSY for good. With equal priorities the same
+            # schedule ran 100 x 2 engines, in turns and from two threads at once, without a stall - and the
+            # priority bought nothing anyway (headline 231.4 vs 231.4 ms, cnn10-fully 303.7 vs 306.0,
+            # femnist50-ring 37.4 vs 37.5). P2PFL_SIDE_PRIO overrides for experiments.
+            self._side = torch.cuda.Stream(device=dev, priority=int(os.environ.get('P2PFL_SIDE_PRIO', '0')))
             # (Tried for few clients, where the side chain is as long as the fused update: the stage-2 weight
-            # gradient on a third stream - two same-priority HIP streams waiting for each other deadlocked now
-            # and then, presumably on one shared hardware queue; and on the main stream in front of the fused
-            # update - no gain over the side stream: 10 clients 313 vs 302 ms, 50 FEMNIST clients 54.6 vs 55.3.)
+            # gradient on a third stream, and on the main stream in front of the fused update - no gain over the
+            # side stream: 10 clients 313 vs 302 ms, 50 FEMNIST clients 54.6 vs 55.3.)
             self._act_pp = [self.act[self.nc - 1], torch.zeros_like(self.act[self.nc - 1])]
 
     def close(self) -> None:
@@ -659,6 +680,15 @@ class HipEngine(ShardEngine):
         step t still reads it while the side stream already produces the one of step t+1.
         """
         main, side = torch.cuda.current_stream(), self._side
+        dbg = self._stream_debug
+        if dbg is not None:
+            dbg.clear()
+
+        def mark(stream, name):          # P2PFL_STREAM_DEBUG=1: named events, so a stall report can say which wait hangs
+            if dbg is not None and not self._capturing:
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                dbg.append((name, ev))
         nv_last = self._nv(n - (steps - 1) * self.B)
         for ph in ("Train", "Validation"):
             self.stats[ph].zero_()
@@ -673,24 +703,24 @@ class HipEngine(ShardEngine):
                 nv = nv_last if s == steps - 1 else self._nv(self.B)
                 t += 1
                 self._dense_step(self._act_pp[(t - 1) & 1], self.train_y, sidx, nv, t, side)
+                mark(main, f"step {t}: main after fused update")
                 with torch.cuda.stream(side):     # under the fused update: kernel variants that fit beside it on a CU
                     self._conv_backward(self.train_x, sidx, coresident=True)
                     self._optim_step(t)
                     if s + 1 < steps:
                         self._conv_forward(self.train_x, self._perm_buf[e, :, (s + 1) * self.B:(s + 2) * self.B],
                                            self._act_pp[t & 1], coresident=True)
+                mark(side, f"step {t}: side after conv bwd/fwd")
                 main.wait_stream(side)
+                mark(main, f"step {t}: main after join")
             if self.val_x is not None:
                 self._eval_pass(self.val_x, self.val_y, "Validation")
 
     def _train(self, epochs: int, steps: int, n: int) -> None:
         self._step_pos = 0
-        # The two-stream schedule only ever exists as branches of a captured graph. Launched eagerly (as the
-        # warm-up before a capture used to do, or with use_graph=False) the same stream / event pattern
-        # stalled on the device now and then - always in the first fit of an engine in a long-lived process,
-        # side stream and launch stream both left busy (tests/conftest.py watchdog) - while replays of the
-        # captured graph never did. Eager launches therefore take the in-order schedule.
-        if self.overlap and self._capturing:
+        # The two-stream schedule runs eagerly (warm-up, use_graph=False) exactly as it is captured: the stall that
+        # once forced eager launches onto the in-order schedule came from the side stream's priority (see __init__).
+        if self.overlap and not os.environ.get("P2PFL_INORDER"):
             self._train_body_pipelined(epochs, steps, n)
         else:
             self._train_body(epochs, steps, n)

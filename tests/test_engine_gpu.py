@@ -156,7 +156,7 @@ def test_prepare_leaves_no_trace():
 
 def test_pipelined_schedule_matches_single_stream():
     """Two-stream schedule (conv kernels under the fused wgrad+Adam; graph branches) == the in-order schedule
-    (also what an engine with overlap runs when it is not capturing)."""
+    and the same two-stream schedule launched eagerly (use_graph=False)."""
     from p2pfl_amd.datasets.synthetic import synthetic_shards
     from p2pfl_amd.models.specs import get_spec
     from p2pfl_amd.runtime.engine import HipEngine

@@ -37,7 +37,11 @@ def test_scenario_on_the_hip_engine(tmp_path, dataset, model, federation, topolo
     cdir = _scenario(tmp_path, 4, federation, dataset, model, rounds=2, topology=topology)
     json.dump([{"round": 1, "action": "kill", "node": 3}], open(os.path.join(cdir, "faults.json"), "w"))
     s = run_scenario(cdir, device="cuda", save_models=True)
-    assert s["nodes"] == 4 and s["rounds"] == 2 and [e[1] for e in s["membership_events"] if e[1] in ("kill", "evicted")] == ["kill", "evicted"]
+    ev = [e[1] for e in s["membership_events"]]
+    assert s["nodes"] == 4 and s["rounds"] == 2 and ev[0] == "kill"
+    # whoever expected node 3's model waited AGGREGATION_TIMEOUT (virtual clock), which is what evicts it; in SDFL
+    # the dead trainer may not be in the leader's train set at all - then nobody waits and it is not evicted yet
+    assert ("evicted" in ev) == ("aggregation_timeout" in ev)
     logs = tmp_path / "logs" / "scen"
     assert "alive False" in open(logs / "participant_3.log").read()
     rows = open(logs / "metrics" / "participant_0" / "metrics.csv").read()

@@ -582,10 +582,9 @@ __global__ __launch_bounds__(256) void conv2_wgrad_reduce_f32_kernel(WgradArgs a
     for (int i = threadIdx.x; i < CIN * T; i += 256) dw[i] = tr[i];
 }
 
-// Dynamic LDS that pads a small-variant block to 86 KB. Two fused-update workgroups (2 x 36 KB) + ONE such block fill
-// the 160 KB of a CU exactly; without the padding the dispatcher packs TWO of the (higher-priority) convolution blocks
-// onto a CU, only one update workgroup still fits beside them and the HBM-bound update runs at 40 % of its rate
-// (measured: 3.0 -> 4.9 ms per step for 100 clients).
+// Optional dynamic LDS padding of a small-variant block (P2PFL_CORES_LDS_KB, experiments): limits how many of them the
+// dispatcher packs onto a CU beside the fused-update workgroups. Measured without effect - what slows the update
+// under fp32 convolutions is the MFMA issue arbitration, not occupancy (profiles/r2_overlap_probe.txt).
 size_t coresident_pad(const void* kernel) {
     static std::mutex mu;
     static std::map<const void*, size_t> pads;
@@ -595,7 +594,7 @@ size_t coresident_pad(const void* kernel) {
     hipFuncAttributes attr;
     size_t pad = 0;
     const char* e = getenv("P2PFL_CORES_LDS_KB");
-    const size_t TARGET = (e ? (size_t)atoi(e) : 64) * 1024;
+    const size_t TARGET = (e ? (size_t)atoi(e) : 0) * 1024;      // measured 0 / 64 / 72 / 80 / 100 KB: no difference
     if (hipFuncGetAttributes(&attr, kernel) == hipSuccess && attr.sharedSizeBytes < TARGET)
         pad = TARGET - attr.sharedSizeBytes;
     pads[kernel] = pad;
@@ -603,6 +602,16 @@ size_t coresident_pad(const void* kernel) {
 }
 #define LAUNCH_SMALL(kernel, grid, block, stream, args) \
     hipLaunchKernelGGL(kernel, grid, block, coresident_pad(reinterpret_cast<const void*>(&kernel)), stream, args)
+
+// The small-footprint variants are the default everywhere: two or three of their blocks share a CU, so one block's
+// staging / epilogue hides under another's MFMAs (femnist1000-star 99.8 -> 95.6 ms, femnist50-ring 99.3 -> 88.6 ms
+// per round; MNIST-CNN shard alone: fwd 0.745 -> 0.717, dgrad 0.820 -> 0.736, wgrad 0.855 -> 0.790 ms).
+// P2PFL_CONV_SMALL=0 selects the one-block-per-CU variants for A/B runs.
+bool want_small(int flags) {
+    static const char* e = getenv("P2PFL_CONV_SMALL");
+    (void)flags;
+    return e ? atoi(e) != 0 : true;
+}
 
 int num_cus() {
     static int n = 0;
@@ -623,7 +632,7 @@ int num_cus() {
 // small (co-resident variant): one row tile per block (twice the blocks), np >= 2 (register budget)
 void wgrad_split_f32(int K, int B, int KS, int cus, bool small, int& np, int& ns) {
     // small: <= 4 accumulators per wave (128-register budget): >= 2 tap parts
-    static const int parts_big[3] = {1, 2, 5}, parts_small5[3] = {2, 3, 5}, parts_small3[3] = {2, 3, 5};
+    static const int parts_big[3] = {1, 2, 5}, parts_small5[3] = {2, 3, 5}, parts_small3[3] = {1, 2, 3};
     const int* parts = !small ? parts_big : (KS == 5 ? parts_small5 : parts_small3);
     const int T = KS * KS;
     double best = -1.0;
@@ -648,7 +657,8 @@ void launch_wgrad(const WgradArgs& a, int np, bool small, hipStream_t stream) {
     const int slots = cdiv(a.K, 8) * 8 * a.NS;
     if (small) {
         const dim3 block(256);
-        if (np == 2) LAUNCH_SMALL((conv2_wgrad_f32_small_kernel<KS, 2>), dim3(slots * 4), block, stream, a);
+        if (np == 1 && KS == 3) LAUNCH_SMALL((conv2_wgrad_f32_small_kernel<3, 1>), dim3(slots * 2), block, stream, a);
+        else if (np <= 2) LAUNCH_SMALL((conv2_wgrad_f32_small_kernel<KS, 2>), dim3(slots * 4), block, stream, a);
         else if (np == 3) LAUNCH_SMALL((conv2_wgrad_f32_small_kernel<KS, 3>), dim3(slots * 6), block, stream, a);
         else LAUNCH_SMALL((conv2_wgrad_f32_small_kernel<KS, 5>), dim3(slots * 10), block, stream, a);
     } else {
@@ -679,7 +689,7 @@ int conv2_fwd_f32(const float* a1, long a1_cs, const float* wp, long wp_cs, cons
     if ((wp_cs & 3) || ((uintptr_t)wp & 15) || ((uintptr_t)a1 & 15) || (a1_cs & 3)) return -2;
     if (((uintptr_t)a2 & 15) || (a2_cs & 3) || ((uintptr_t)code & 15) || (c_cs & 15)) return -2;   // 16-byte block stores
     FwdArgs a{a1, a1_cs, wp, wp_cs, bias, b_cs, a2, a2_cs, code, c_cs, K, B};
-    if (flags & CONV_CORESIDENT) {
+    if (want_small(flags)) {
         dim3 grid(cdiv(K, 8) * 8 * B);
         if (KS == 5) LAUNCH_SMALL(conv2_fwd_f32_small_kernel<5>, grid, dim3(256), stream, a);
         else if (KS == 3) LAUNCH_SMALL(conv2_fwd_f32_small_kernel<3>, grid, dim3(256), stream, a);
@@ -699,7 +709,7 @@ int conv2_dgrad_f32(const float* g, long g_cs, const uint8_t* code, long c_cs, c
     if ((wp_cs & 3) || ((uintptr_t)wp & 15) || (da1_cs & 3) || ((uintptr_t)da1 & 15)) return -2;
     DgradArgs a{g, g_cs, code, c_cs, wp, wp_cs, da1, da1_cs, K, B};
     dim3 grid(cdiv(K, 8) * 8 * B);
-    const bool small = flags & CONV_CORESIDENT;
+    const bool small = want_small(flags);
     if (KS == 5 && small) LAUNCH_SMALL(conv2_dgrad_f32_small_kernel<5>, grid, dim3(256), stream, a);
     else if (KS == 5) hipLaunchKernelGGL(conv2_dgrad_f32_kernel<5>, grid, dim3(256), 0, stream, a);
     else if (KS == 3 && small) LAUNCH_SMALL(conv2_dgrad_f32_small_kernel<3>, grid, dim3(256), stream, a);
@@ -722,7 +732,7 @@ int conv2_wgrad_f32(const float* g, long g_cs, const uint8_t* code, long c_cs, c
                     int flags, hipStream_t stream) {
     if (K <= 0 || B <= 0) return -1;
     if (((uintptr_t)a1 & 15) || (a1_cs & 3)) return -2;
-    const bool small = flags & CONV_CORESIDENT;
+    const bool small = want_small(flags);
     int np, ns;
     wgrad_split_f32(K, B, KS, num_cus(), small, np, ns);
     if (scratch == nullptr || scratch_floats < (long)K * ns * (KS * KS * COUT * CIN + COUT)) ns = 1;

@@ -102,3 +102,24 @@ if os.path.exists(lib_path) and prec == "fp32":
     tm_, _ = timed(None, fm)
     tb, (a_, b_) = timed(fv, fm)
     print(f"  valu burn alone {tv:.3f}, mfma burn alone {tm_:.3f}, together {tb:.3f} (valu {a_:.3f}, mfma {b_:.3f})")
+
+    # whole CUs taken away from the update kernel (LDS-hogging sleepers): how many can it spare?
+    burn.burn_hog_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    for blocks in (32, 64, 96, 128, 160):
+        fh = lambda: burn.burn_hog_launch(blocks, 4000, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        fh()
+        th, _ = timed(None, fh)
+        # hog first (side), then the update on main: the hogs are resident for the update's whole duration
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+            with torch.cuda.stream(side):
+                fh()
+            time_sleep = __import__("time").sleep(0.0005)
+            e0.record()
+            update()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        print(f"  {blocks:3d} CUs hogged (sleep {th:.2f} ms): update {best:.3f} ms")

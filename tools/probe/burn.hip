@@ -40,6 +40,19 @@ extern "C" __global__ __launch_bounds__(256) void burn_sleep(float* out, int ite
     for (int i = 0; i < iters; ++i) __builtin_amdgcn_s_sleep(64);
     if (seed == 12345.678f) out[0] = seed;
 }
+// occupies a whole CU (dynamic LDS of ~150 KB: nothing else fits beside it) and does nothing: how does the HBM-bound
+// update kernel fare on the CUs that are left?
+extern "C" __global__ __launch_bounds__(64) void burn_hog(float* out, int iters, float seed) {
+    extern __shared__ float lds[];
+    if (seed == 12345.678f) lds[threadIdx.x] = seed;
+    for (int i = 0; i < iters; ++i) __builtin_amdgcn_s_sleep(64);
+    if (seed == 12345.678f) out[0] = lds[threadIdx.x];
+}
+extern "C" int burn_hog_launch(int blocks, int iters, float* out, hipStream_t s) {
+    hipFuncSetAttribute((const void*)burn_hog, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipLaunchKernelGGL(burn_hog, dim3(blocks), dim3(64), 150 * 1024, s, out, iters, 1.0f);
+    return (int)hipGetLastError();
+}
 extern "C" int burn_launch(int which, int blocks, int iters, float* out, hipStream_t s) {
     if (which == 0) hipLaunchKernelGGL(burn_mfma_f32, dim3(blocks), dim3(256), 0, s, out, iters, 1.0f);
     else if (which == 1) hipLaunchKernelGGL(burn_mfma_bf16, dim3(blocks), dim3(256), 0, s, out, iters, 1.0f);

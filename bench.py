@@ -94,7 +94,7 @@ def main() -> None:
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--batch-size", type=int, default=32)
     ap.add_argument("--impl", default="hip", choices=["hip", "eager"])
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp32-split", "bf16"],
                     help="precision of the matrix products of the HIP engine (fp32 = the reference's precision)")
     ap.add_argument("--save-baseline", action="store_true",
                     help="with --impl eager on the headline config: record the result as profiles/eager_baseline.json")

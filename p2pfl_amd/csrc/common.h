@@ -16,8 +16,15 @@ constexpr int WAVE = 64;
 // Precision policy of the matrix products (argument `prec` of the launchers):
 //   PREC_F32  - fp32 operands on v_mfma_f32_32x32x2_f32: exact fp32 fma chains, the reference's precision
 //   PREC_BF16 - operands rounded to bf16, fp32 accumulation (16x the matrix-core rate)
+//   PREC_F32_SPLIT - as PREC_F32, except that the stage-2 convolutions (the MFMA-bound kernels of the step) form their
+//               fp32 products from three bf16 terms per operand, a = a0 + a1 + a2 EXACTLY (3 x 8 significand bits),
+//               keeping the six products a_i * b_j with i + j <= 2 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
+//               every kept product is exact, the dropped ones are <= 2^-24 |a b| (below half an fp32 ulp of the
+//               product), and six bf16 MFMAs cost 192 matrix-core cycles where the fp32 MFMAs of the same 16-deep
+//               chunk cost 512. Everything else (storage, dense layers, stage 1) is identical to PREC_F32.
 constexpr int PREC_BF16 = 0;
 constexpr int PREC_F32 = 1;
+constexpr int PREC_F32_SPLIT = 2;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
@@ -27,6 +34,23 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(const float* v) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) r[i] = (__bf16)v[i];
     return r;
+}
+
+// 8 fp32 -> NS bf16 terms whose sum is the input (exactly for NS == 3; NS == 1 is the plain rounding): each term
+// is the RNE rounding of what the previous terms left over, so terms shrink by >= 2^-8 per level.
+template <int NS>
+__device__ __forceinline__ void split_bf16x8(const float* v, bf16x8 (&out)[NS]) {
+    float r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = v[i];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        out[s] = pack_bf16x8(r);
+        if (s + 1 < NS) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] -= (float)out[s][i];
+        }
+    }
 }
 
 __device__ __forceinline__ float wave_reduce_sum(float v) {

@@ -346,7 +346,7 @@ P2PFL_API int p2pfl_conv1_fwd(const float* data, long data_cs, const int* sidx, 
                               const float* w, long w_cs, const float* bias, long b_cs, float* a1,
                               long a_cs, uint8_t* code, long c_cs, int K, int B, int F, int KS, int prec,
                               hipStream_t stream) {
-    if (prec == PREC_F32)
+    if (prec != PREC_BF16)
         return conv1_fwd_f32(data, data_cs, sidx, sidx_cs, w, w_cs, bias, b_cs, a1, a_cs, code, c_cs, K, B, F, KS, stream);
     if (K <= 0 || B <= 0 || F <= 0 || F > 32) return -1;
     if (((uintptr_t)data & 15) || (data_cs & 3)) return -2;      // float4 loads of whole 784-pixel images
@@ -367,7 +367,7 @@ P2PFL_API int p2pfl_conv1_wgrad(const float* g, long g_cs, const uint8_t* code, 
                                 const float* data, long data_cs, const int* sidx, long sidx_cs,
                                 float* dw, long dw_cs, float* db, long db_cs, int K, int B, int F,
                                 int KS, int prec, hipStream_t stream) {
-    if (prec == PREC_F32)
+    if (prec != PREC_BF16)
         return conv1_wgrad_f32(g, g_cs, code, c_cs, data, data_cs, sidx, sidx_cs, dw, dw_cs, db, db_cs, K, B, F, KS,
                                stream);
     if (K <= 0 || B <= 0 || F <= 0 || F > 32) return -1;

@@ -483,7 +483,7 @@ P2PFL_API int p2pfl_linear_wgrad_adam(const float* dy, long dy_cs, const float* 
     // many clients: the side branch has slack and three resident workgroups stream a little faster
     const char* pin_env = getenv("P2PFL_PIN_UPDATE");
     const bool pin = pin_env ? atoi(pin_env) != 0 : K <= PIN_UPDATE_MAX_CLIENTS;
-    if (prec == PREC_F32) {
+    if (prec != PREC_BF16) {
         if (fresh) hipLaunchKernelGGL((linear_wgrad_adam_kernel<4, 1, true, 0, float>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((linear_wgrad_adam_kernel<4, 1, false, 0, float>), grid, dim3(256), 0, stream, a);
     } else if (pin) {
@@ -505,7 +505,7 @@ P2PFL_API int p2pfl_linear_wgrad_sgdm(const float* dy, long dy_cs, const float* 
     WgradSgdmArgs a{dy, dy_cs, x, x_cs, w, mw, w_cs, b, mb, b_cs, B, In, Out, lr, momentum, weight_decay, fresh,
                     sidx, s_cs};
     const dim3 grid(cdiv(In + 1, 128), cdiv(Out, 128), K);
-    if (prec == PREC_F32) {
+    if (prec != PREC_BF16) {
         if (fresh) hipLaunchKernelGGL((linear_wgrad_sgdm_kernel<true, float>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((linear_wgrad_sgdm_kernel<false, float>), grid, dim3(256), 0, stream, a);
     } else {
@@ -546,7 +546,7 @@ P2PFL_API int p2pfl_linear_fwd(const float* x, long x_cs, const float* w, long w
         const int nt = Out <= 32 ? 1 : 2;
         if (scratch == nullptr || scratch_floats < (long)K * cdiv(B, 32) * ks * nt * 1024) ks = 1;
         const dim3 sgrid(ks, cdiv(B, 32), K), rgrid(1, cdiv(B, 32), K);
-        const bool f32 = prec == PREC_F32;
+        const bool f32 = prec != PREC_BF16;
         if (nt == 1 && f32) hipLaunchKernelGGL((linear_fwd_skinny_kernel<1, 4, true>), sgrid, dim3(1024), 0, stream, a);
         else if (nt == 1) hipLaunchKernelGGL((linear_fwd_skinny_kernel<1, 4, false>), sgrid, dim3(1024), 0, stream, a);
         else if (f32) hipLaunchKernelGGL((linear_fwd_skinny_kernel<2, 2, true>), sgrid, dim3(1024), 0, stream, a);
@@ -564,7 +564,7 @@ P2PFL_API int p2pfl_linear_fwd(const float* x, long x_cs, const float* w, long w
     const bool sparse_grid = (long)grid.x * grid.y * grid.z <= num_cus() && getenv("P2PFL_NO_BK128") == nullptr;
     // (single-buffered 64- / 128-deep variants: 528 us against 516-528 double-buffered 64-deep; 128-deep x 2: 640;
     //  32 x 64 tiles with 2 waves, i.e. twice the blocks: 549 us with 64-deep, 609 us with 128-deep steps)
-    if (prec == PREC_F32) {
+    if (prec != PREC_BF16) {
         // fp32 tiles are twice the bytes: 32-deep steps x 2 buffers = the LDS footprint (46 KB, 3 workgroups per
         // CU) of the 64-deep bf16 variant; 64-deep (87 KB, one workgroup per CU) only for grids below one block per CU
         if (In >= 1024 && sparse_grid) hipLaunchKernelGGL((linear_fwd_kernel<64, 2, float>), grid, dim3(256), 0, stream, a);
@@ -585,7 +585,7 @@ P2PFL_API int p2pfl_linear_dgrad(const float* dy, long dy_cs, const float* w, lo
     DgradArgs a{dy, dy_cs, w, w_cs, act, act_cs, dx, dx_cs, B, In, Out, vec};
     dim3 grid(cdiv(In, 128), cdiv(B, 32), K);
     const bool sparse_grid = (long)grid.x * grid.y * grid.z <= num_cus() && getenv("P2PFL_NO_BK128") == nullptr;
-    if (prec == PREC_F32) {
+    if (prec != PREC_BF16) {
         if (Out >= 1024 && sparse_grid) hipLaunchKernelGGL((linear_dgrad_kernel<64, 2, float>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((linear_dgrad_kernel<32, 2, float>), grid, dim3(256), 0, stream, a);
     }
@@ -601,7 +601,7 @@ P2PFL_API int p2pfl_linear_wgrad(const float* dy, long dy_cs, const float* x, lo
     if (K <= 0 || B <= 0 || In <= 0 || Out <= 0) return -1;
     WgradArgs a{dy, dy_cs, x, x_cs, dw, dw_cs, db, db_cs, B, In, Out, sidx, s_cs};
     dim3 grid(cdiv(In + 1, 128), cdiv(Out, 128), K);
-    if (prec == PREC_F32) hipLaunchKernelGGL(linear_wgrad_kernel<float>, grid, dim3(256), 0, stream, a);
+    if (prec != PREC_BF16) hipLaunchKernelGGL(linear_wgrad_kernel<float>, grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(linear_wgrad_kernel<__bf16>, grid, dim3(256), 0, stream, a);
     P2PFL_RETURN_LAST_ERROR();
 }

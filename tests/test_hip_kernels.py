@@ -21,7 +21,7 @@ def hip():
     return h
 
 
-@pytest.fixture(params=["fp32", "bf16"])
+@pytest.fixture(params=["fp32", "fp32-split", "bf16"])
 def prec(request):
     """Runs the test once per precision policy, as the default of every product wrapper."""
     from p2pfl_amd.ops import hip as h
@@ -31,8 +31,8 @@ def prec(request):
     h.set_default_precision(old)
 
 
-TOL_DENSE = {"fp32": 2e-5, "bf16": 2e-2}
-TOL_CONV = {"fp32": 2e-4, "bf16": 2e-2}
+TOL_DENSE = {"fp32": 2e-5, "fp32-split": 2e-5, "bf16": 2e-2}
+TOL_CONV = {"fp32": 2e-4, "fp32-split": 2e-4, "bf16": 2e-2}
 
 
 def rel_err(a, b):
@@ -300,7 +300,7 @@ def test_conv2_wgrad_dgrad(ks, B, K, prec, cores):
     h.conv2_wgrad(g, code, a1, dw, db, ks, coresident=cores)
     h.conv2_dgrad(g, code, w, da1, ks, coresident=cores)
     dpre = route(g, code, 7)   # [K,B,Cout,14,14]
-    for k in range(K if K <= 16 else 0, K, 1) if K <= 16 else range(0, K, 13):
+    for k in (range(K) if K <= 16 else range(0, K, 13)):
         x = a1[k].view(B, Cin, 14, 14)
         wk = w[k].reshape(Cout, Cin, ks, ks)
         ref_w = torch.nn.grad.conv2d_weight(x, wk.shape, dpre[k], padding=ks // 2).reshape(Cout, -1)
@@ -308,6 +308,48 @@ def test_conv2_wgrad_dgrad(ks, B, K, prec, cores):
         assert rel_err(dw[k], ref_w) < TOL_CONV[prec]
         assert rel_err(db[k], dpre[k].sum(dim=(0, 2, 3))) < TOL_CONV[prec]
         assert rel_err(da1[k], ref_x) < TOL_CONV[prec]
+
+
+@pytest.mark.parametrize("ks", [5, 3])
+def test_conv2_split_is_fp32_accurate(ks):
+    """The three-term bf16 split (fp32-split) against a float64 oracle: its error must be in the class of the fp32
+    MFMA kernels' own rounding error (both accumulate in fp32), nowhere near bf16's."""
+    h = hip()
+    K, B, Cin, Cout = 2, 16, 32, 64
+    a1 = torch.randn(K, B, Cin, 196, device=DEV).relu()
+    w = slab_view(K, (Cout, Cin * ks * ks)) * 0.05
+    b = slab_view(K, (Cout,)) * 0.1
+    g = torch.randn(K, B, Cout, 49, device=DEV)
+    err = {}
+    for prec in ("fp32", "fp32-split", "bf16"):
+        a2 = torch.empty(K, B, Cout, 49, device=DEV)
+        code = torch.empty(K, B, Cout, 49, dtype=torch.uint8, device=DEV)
+        dw = slab_view(K, (Cout, Cin * ks * ks))
+        db = slab_view(K, (Cout,))
+        da1 = torch.empty(K, B, Cin, 196, device=DEV)
+        h.conv2_fwd(a1, w, b, a2, code, ks, prec=prec)
+        h.conv2_wgrad(g, code, a1, dw, db, ks, prec=prec)
+        h.conv2_dgrad(g, code, w, da1, ks, prec=prec)
+        dpre = route(g, code, 7).double()
+        e = [0.0, 0.0, 0.0, 0.0]
+        for k in range(K):
+            x = a1[k].view(B, Cin, 14, 14).double()
+            wk = w[k].reshape(Cout, Cin, ks, ks).double()
+            pre = F.conv2d(x, wk, b[k].double(), padding=ks // 2)
+            ref = F.max_pool2d(pre.relu(), 2, 2).reshape(B, Cout, 49)
+            # pooling picks may differ between precisions only on near-ties; compare the pooled values
+            e[0] = max(e[0], rel_err(a2[k].double(), ref))
+            e[1] = max(e[1], rel_err(dw[k].double(), torch.nn.grad.conv2d_weight(x, wk.shape, dpre[k], padding=ks // 2)
+                                     .reshape(Cout, -1)))
+            e[2] = max(e[2], rel_err(da1[k].double(), torch.nn.grad.conv2d_input(x.shape, wk, dpre[k], padding=ks // 2)
+                                     .reshape(B, Cin, 196)))
+            e[3] = max(e[3], rel_err(db[k].double(), dpre[k].sum(dim=(0, 2, 3))))
+        err[prec] = e
+    print("conv2 max rel err vs float64 [fwd, wgrad, dgrad, bias]:", err)
+    for i in range(4):
+        assert err["fp32-split"][i] < 4 * err["fp32"][i] + 2e-7, (i, err)
+        assert err["fp32-split"][i] < 5e-6, (i, err)
+    assert err["bf16"][0] > 100 * err["fp32-split"][0]
 
 
 @pytest.mark.parametrize("C,B,nv", [(10, 32, 32), (62, 32, 28), (10, 100, 77), (62, 256, 200), (17, 40, 40), (64, 5, 3)])

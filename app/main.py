@@ -34,6 +34,9 @@ argparser.add_argument("-h", "--help", action="help", default=argparse.SUPPRESS,
 # MI355X additions
 argparser.add_argument("--engine", default="auto", choices=["auto", "batched", "process"], help="batched: one process per GPU hosting all nodes; process: one OS process per node")
 argparser.add_argument("--gpus", type=int, default=None, help="GPUs (ranks) for the batched engine")
+argparser.add_argument("--control-plane", dest="control_plane", action="store_true", help="batched engine: serve the node protocol (heartbeats, roles, START/STOP_LEARNING, status reports) for the co-resident nodes")
+argparser.add_argument("--gateway", action="append", default=[], metavar="IDX[:PORT]", help="batched engine: TCP endpoint of virtual node IDX for reference-protocol peers (repeatable)")
+argparser.add_argument("--wait-start", dest="wait_start", type=float, default=None, help="with --gateway: wait this many seconds for START_LEARNING from an external node")
 argparser.add_argument("--encrypt", action="store_true", help="encrypt model exchange / peer links")
 argparser.add_argument("--scenario-name", dest="scenario_name", default=None)
 argparser.add_argument("--nodes", type=int, default=0, help="generate an N-node scenario into --config before starting")

@@ -34,6 +34,23 @@ _RSA_KEY_B64_LEN = 216     # base64(DER SPKI) of an RSA-1024 key
 _RSA_BLOCK_LEN = 128
 
 
+def _recv_line(s: socket.socket, limit: int) -> bytes:
+    """The handshake line, up to and including its newline, and NOT A BYTE MORE: a dialling node may send
+    START_LEARNING / its first PARAMS fragments right behind ``CONNECT ...\n``; a plain ``recv(BLOCK_SIZE)`` here
+    (what the reference does, base_node.py:229) swallows them with the handshake and the peer never starts."""
+    out = b""
+    while len(out) < limit:
+        peek = s.recv(limit - len(out), socket.MSG_PEEK)
+        if not peek:
+            break
+        pos = peek.find(b"\n")
+        take = len(peek) if pos < 0 else pos + 1
+        out += _recv_exact(s, take)
+        if pos >= 0:
+            break
+    return out
+
+
 def _recv_exact(s: socket.socket, n: int) -> bytes:
     out = b""
     while len(out) < n:
@@ -178,7 +195,7 @@ class BaseNode(threading.Thread, Observer):
                     ns.close()
                     break
                 ns.settimeout(5)
-                msg = ns.recv(int(self.config.participant["BLOCK_SIZE"]))
+                msg = _recv_line(ns, int(self.config.participant["BLOCK_SIZE"]))
                 if msg:
                     callback = lambda h, p, fu, fc: self.__process_new_connection(ns, h, p, fu, fc)
                     if not CommunicationProtocol.process_connection(msg, callback):

@@ -71,6 +71,11 @@ class Controller:
         self.matrix = g("matrix")
         self.engine = g("engine", "auto")          # auto | batched | process
         self.gpus = g("gpus")                      # number of GPUs for the batched engine (None: all visible)
+        # batched engine, one rank: serve the node protocol for the co-resident nodes (runtime/host.py) and open
+        # TCP gateways ("IDX[:PORT]") through which reference-protocol nodes peer with virtual node IDX
+        self.control_plane = bool(g("control_plane", False))
+        self.gateways = list(g("gateway", None) or [])
+        self.wait_start = g("wait_start", None)
         self.encrypt = bool(g("encrypt", False))
         self.network_subnet = g("network_subnet")
         self.network_gateway = g("network_gateway")
@@ -301,11 +306,19 @@ class Controller:
             self.start_nodes_cmd(idx_start_node)
 
     def _use_batched(self) -> bool:
-        if self.engine == "process":
-            return False
         p0 = self.config.participants[0]
         pair = (p0["data_args"]["dataset"], p0["model_args"]["model"])
         homogeneous = all((p["data_args"]["dataset"], p["model_args"]["model"]) == pair for p in self.config.participants)
+        if self.engine == "process":
+            if homogeneous and pair in BATCHED_PAIRS and any(
+                    p["device_args"].get("accelerator") in ("gpu", "auto") for p in self.config.participants):
+                # compatibility path: every OS process drives its own one-client engine (K = 1 launches, a host
+                # round trip per payload, the TCP pacing constants) - two orders of magnitude below the batched path
+                logging.warning("--engine process with a GPU accelerator runs ONE client per kernel launch and per "
+                                "process; %s / %s is supported by the client-batched runtime: drop --engine process "
+                                "(or pass --engine batched) to host all %d nodes in one process per GPU",
+                                pair[0], pair[1], self.n_nodes)
+            return False
         if self.engine == "batched":
             # every family of the factory runs batched (kernel-level specs on the HIP engine, the others as
             # nn.Modules on stock ops with their state in the slab) - but all nodes must run the same one
@@ -365,6 +378,13 @@ class Controller:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = dict(os.environ, PYTHONPATH=root)
         args = [self.config_dir] + (["--encrypt"] if self.encrypt else [])
+        if self.control_plane or self.gateways:
+            if world > 1:
+                logging.warning("the control plane / TCP gateways serve one rank: running the scenario on 1 GPU")
+                world = 1
+            args += ["--control-plane"] + [x for g in self.gateways for x in ("--gateway", str(g))]
+            if self.wait_start is not None:
+                args += ["--wait-start", str(self.wait_start)]
         if world > 1:
             cmd = [self.python_path, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                    "--master-addr", "127.0.0.1", "--master-port", str(29500 + os.getpid() % 1000),

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from ..datamodule import FederatedDataModule, synthetic_classification
+from ..datamodule import FederatedDataModule, synthetic_classification, LOAD_LOCK
 
 MEAN = torch.tensor([0.4914, 0.4822, 0.4465]).view(1, 3, 1, 1)
 STD = torch.tensor([0.2470, 0.2435, 0.2616]).view(1, 3, 1, 1)
@@ -33,8 +33,9 @@ class CIFAR10DataModule(FederatedDataModule):
                  root_dir=None, seed=0):
         super().__init__(sub_id, number_sub, batch_size, num_workers, val_percent, iid, seed)
         cls = CIFAR10DataModule
-        if cls.cifar10_train is None:
-            cls._load(root_dir or os.path.join(os.getcwd(), "data"))
+        with LOAD_LOCK:
+            if cls.cifar10_train is None:
+                cls._load(root_dir or os.path.join(os.getcwd(), "data"))
         self._install(*cls.cifar10_train, *cls.cifar10_val, drop_val=True)
         self.val_x, self.val_y = self.test_x, self.test_y   # reference: val loader == test loader
 

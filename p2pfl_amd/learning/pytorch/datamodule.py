@@ -14,12 +14,17 @@ and the same contiguous block of the test set (mnist/mnist.py:100-118).
 from __future__ import annotations
 
 import logging
+import threading
 from math import floor
 from typing import Tuple
 
 import torch
 from torch.utils.data import DataLoader, TensorDataset
 
+
+# the data modules cache the full dataset on their class: one loader at a time (nodes of one process are built
+# from several threads - gateways, tests - and a second concurrent load replaced tensors another thread was slicing)
+LOAD_LOCK = threading.RLock()
 
 class FederatedDataModule:
     num_classes = 10

@@ -15,7 +15,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from ..datamodule import FederatedDataModule, synthetic_classification
+from ..datamodule import FederatedDataModule, synthetic_classification, LOAD_LOCK
 
 
 def femnist_transform(x: torch.Tensor, contrast_jitter: bool = False, generator=None) -> torch.Tensor:
@@ -42,8 +42,9 @@ class FEMNISTDataModule(FederatedDataModule):
                  root_dir=None, seed=0, contrast_jitter=False):
         super().__init__(sub_id, number_sub, batch_size, num_workers, val_percent, iid, seed)
         cls = FEMNISTDataModule
-        if cls.femnist_train is None or cls.femnist_val is None:
-            cls._load(root_dir or os.path.join(os.getcwd(), "data", "FEMNIST"), contrast_jitter)
+        with LOAD_LOCK:
+            if cls.femnist_train is None or cls.femnist_val is None:
+                cls._load(root_dir or os.path.join(os.getcwd(), "data", "FEMNIST"), contrast_jitter)
         self._install(*cls.femnist_train, *cls.femnist_val)
 
     @classmethod

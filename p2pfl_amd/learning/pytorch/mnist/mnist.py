@@ -16,7 +16,7 @@ import struct
 import numpy as np
 import torch
 
-from ..datamodule import FederatedDataModule, synthetic_classification
+from ..datamodule import FederatedDataModule, synthetic_classification, LOAD_LOCK
 
 
 def _read_idx(path: str) -> np.ndarray:
@@ -48,8 +48,9 @@ class MNISTDataModule(FederatedDataModule):
                  root_dir=None, seed=0):
         super().__init__(sub_id, number_sub, batch_size, num_workers, val_percent, iid, seed)
         cls = MNISTDataModule
-        if cls.mnist_train is None or cls.mnist_val is None:
-            cls._load(root_dir or os.path.join(os.getcwd(), "data"), seed)
+        with LOAD_LOCK:
+            if cls.mnist_train is None or cls.mnist_val is None:
+                cls._load(root_dir or os.path.join(os.getcwd(), "data"), seed)
         self._install(*cls.mnist_train, *cls.mnist_val)
 
     @classmethod

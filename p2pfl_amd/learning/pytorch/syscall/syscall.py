@@ -23,7 +23,7 @@ import os
 
 import torch
 
-from ..datamodule import FederatedDataModule, synthetic_classification
+from ..datamodule import FederatedDataModule, synthetic_classification, LOAD_LOCK
 
 
 FEATURE = "system calls frequency_1gram-scaled"
@@ -59,8 +59,9 @@ class SYSCALLDataModule(FederatedDataModule):
                  root_dir=None, seed=0):
         super().__init__(sub_id, number_sub, batch_size, num_workers, val_percent, iid, seed)
         cls = SYSCALLDataModule
-        if cls.train_set is None:
-            cls._load(root_dir or os.path.join(os.getcwd(), "data", "syscall"))
+        with LOAD_LOCK:
+            if cls.train_set is None:
+                cls._load(root_dir or os.path.join(os.getcwd(), "data", "syscall"))
         self._install(*cls.train_set, *cls.test_set)
 
     @classmethod

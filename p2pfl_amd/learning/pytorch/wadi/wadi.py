@@ -11,7 +11,7 @@ import os
 import numpy as np
 import torch
 
-from ..datamodule import FederatedDataModule, synthetic_classification
+from ..datamodule import FederatedDataModule, synthetic_classification, LOAD_LOCK
 
 
 class WADIDataModule(FederatedDataModule):
@@ -25,8 +25,9 @@ class WADIDataModule(FederatedDataModule):
                  root_dir=None, seed=0):
         super().__init__(sub_id, number_sub, batch_size, num_workers, val_percent, iid, seed)
         cls = WADIDataModule
-        if cls.train_set is None:
-            cls._load(root_dir or os.path.join(os.getcwd(), "data", "WADI"))
+        with LOAD_LOCK:
+            if cls.train_set is None:
+                cls._load(root_dir or os.path.join(os.getcwd(), "data", "WADI"))
         self._install(*cls.train_set, *cls.test_set)
 
     @classmethod

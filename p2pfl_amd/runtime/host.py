@@ -367,6 +367,7 @@ class FederationHost:
         self.epochs = fed.epochs
         self.reports = []
         self.status_poster = status_poster             # fn(node idx, participant dict) for the controller POST
+        self.round_callback: Optional[Callable] = None # fn(RoundReport) after every round (learning thread)
         self._stop = threading.Event()                 # stop the learning loop
         self._terminate = threading.Event()            # stop the service thread
         self._init_ready = threading.Event()
@@ -392,6 +393,23 @@ class FederationHost:
         self._service = threading.Thread(target=self._serve, name="federation-host", daemon=True)
         self._service.start()
         return self
+
+    def wait_started(self, timeout: Optional[float] = None) -> bool:
+        """Block until learning runs (a START_LEARNING from a gateway's peer, or :meth:`start_learning`)."""
+        end = None if timeout is None else time.time() + timeout
+        while self._learning_thread is None:
+            if end is not None and time.time() > end:
+                return False
+            time.sleep(0.05)
+        return True
+
+    def wait_finished(self, timeout: Optional[float] = None) -> bool:
+        """Block until the learning thread has ended (all rounds done or STOP_LEARNING)."""
+        t = self._learning_thread
+        if t is None:
+            return True
+        t.join(timeout)
+        return not t.is_alive()
 
     def stop(self) -> None:
         self.stop_learning()
@@ -573,7 +591,8 @@ class FederationHost:
             while not self._stop.is_set() and self.round is not None and self.round < self.totalrounds:
                 rep = fed.run_round()
                 self.reports.append(rep)
-                lo = fed.local.start
+                if self.round_callback is not None:
+                    self.round_callback(rep)
                 for i in fed.local:
                     if fed.alive[i]:
                         self.bus.publish(i, CommunicationProtocol.build_models_ready_msg(self.round))

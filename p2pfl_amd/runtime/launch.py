@@ -72,8 +72,27 @@ def load_faults(config_dir: str, parts: List[dict]) -> List[dict]:
     return out
 
 
+def _parse_gateway(text: str):
+    """"IDX", "IDX:PORT" or "IDX:HOST:PORT" -> (virtual node index, listen host or None, port or None)."""
+    bits = str(text).split(":")
+    if len(bits) == 1:
+        return int(bits[0]), None, None
+    if len(bits) == 2:
+        return int(bits[0]), None, int(bits[1])
+    return int(bits[0]), bits[1], int(bits[2])
+
+
 def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, save_models: bool = False,
-                 rounds: int = None, resume: str = None, virtual_devices: int = 1) -> dict:
+                 rounds: int = None, resume: str = None, virtual_devices: int = 1, control_plane: bool = False,
+                 gateways=(), wait_start: float = None) -> dict:
+    """Run the scenario of ``config_dir`` on this rank's GPU.
+
+    ``control_plane`` (one rank): the co-resident nodes get the reference's protocol behaviour from a
+    :class:`~p2pfl_amd.runtime.host.FederationHost` - BEAT / ROLE / MODELS_READY on an in-process bus, status POSTs
+    per node, and for every ``gateways`` entry (``IDX[:PORT]``) a TCP endpoint through which reference-protocol
+    ``Node`` processes peer with virtual node IDX. ``wait_start`` (seconds): do not start by ourselves, wait that
+    long for a START_LEARNING from such a peer (fedstellar/node.py:224-271).
+    """
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -195,8 +214,11 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
     rounds = max(total_rounds - first_round, 0)
     if rounds == 0:
         logging.warning("resumed at round %d of %d: nothing left to do", first_round, total_rounds)
-    for r in range(first_round, total_rounds):
-        rep = fed.run_round()
+    done = [0]
+
+    def after_round(r, rep):
+        nonlocal total_samples
+        done[0] += 1
         total_samples += rep.train_samples
         test = fed.engine.stats["Test"].summary()
         train = fed.engine.stats["Train"].summary()
@@ -213,8 +235,36 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
             loggers[i].log_metrics_direct(m, r)
             node_log(i, f"round {r} role {fed.roles[i]} alive {bool(fed.alive[i])} test_loss {m['Test/Loss']:.4f} "
                         f"test_acc {m['TestEpoch/Accuracy']:.4f} ({rep.seconds:.3f}s)")
-            if r % 2 == 0:
+            if r % 2 == 0 and not control_plane:
                 post_status(i)
+
+    if control_plane or gateways:
+        if world > 1:
+            raise ValueError("--control-plane hosts one rank: run it with one process (the other ranks' nodes are "
+                             "reached through the collective exchange, not the command bus)")
+        from .host import FederationHost
+        names = [f"{p['network_args']['ip']}:{p['network_args']['port']}" for p in parts]
+        host = FederationHost(fed, names=names, scenario=scenario, participant=p0,
+                              status_poster=lambda i, view: post_status(i))
+        host.round_callback = lambda rep: after_round(first_round + len(host.reports) - 1, rep)
+        host.start()
+        for g in gateways:
+            vidx, gh, gp = _parse_gateway(g)
+            gw = host.gateway(vidx, gh or parts[vidx]["network_args"]["ip"], gp)
+            node_log(vidx, f"TCP gateway of virtual node {vidx} listening on {gw.get_name()}")
+        if wait_start is not None:
+            if not host.wait_started(wait_start):
+                logging.warning("no START_LEARNING within %.0f s: starting locally", wait_start)
+                host.start_learning(rounds, epochs)
+        else:
+            host.start_learning(rounds, epochs)
+        host.wait_started(30)
+        host.wait_finished()
+        host.stop()
+        rounds = done[0]
+    else:
+        for r in range(first_round, total_rounds):
+            after_round(r, fed.run_round())
     final = fed.engine.evaluate()
     elapsed = time.time() - t0
     if save_models:
@@ -249,13 +299,21 @@ def main(argv=None):
     ap.add_argument("--rounds", type=int, default=None,
                     help="total rounds of the experiment (default: scenario_args.rounds); a --resume run does the remaining ones")
     ap.add_argument("--resume", default=None, help="directory with participant_<i>_final.ckpt files to start from")
+    ap.add_argument("--control-plane", action="store_true",
+                    help="serve the reference's node protocol for the co-resident nodes (heartbeats, roles, "
+                         "MODELS_READY, status POSTs; START/STOP_LEARNING honoured) - one rank")
+    ap.add_argument("--gateway", action="append", default=[], metavar="IDX[:PORT]",
+                    help="open a TCP endpoint for virtual node IDX so reference-protocol nodes can peer with it "
+                         "(implies --control-plane; repeatable)")
+    ap.add_argument("--wait-start", type=float, default=None, metavar="SECONDS",
+                    help="with a gateway: wait this long for START_LEARNING from an external node instead of starting")
     ap.add_argument("--virtual-devices", type=int, default=1,
                     help="one-GPU runs: split the nodes into this many virtual devices whose exchange takes the "
                          "inter-GPU path (staging + per-link AES with --encrypt)")
     a = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO)
     print(json.dumps(run_scenario(a.config_dir, a.device, a.encrypt, a.save_models, a.rounds, a.resume,
-                                  a.virtual_devices)), flush=True)
+                                  a.virtual_devices, a.control_plane, a.gateway, a.wait_start)), flush=True)
 
 
 if __name__ == "__main__":

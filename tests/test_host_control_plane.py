@@ -172,3 +172,63 @@ def test_stop_learning_from_the_tcp_node_ends_the_batched_run():
         ext.stop()
         host.stop()
         time.sleep(0.3)
+
+
+def test_batched_launcher_serves_the_control_plane(tmp_path, monkeypatch):
+    """`python -m p2pfl_amd.runtime.launch --control-plane --gateway 0:PORT --wait-start S`: the launcher's federation
+    is started by START_LEARNING from a reference-protocol TCP node that peers with virtual node 0, runs the rounds
+    that node asked for, and logs them per participant like the plain launcher."""
+    import json
+    import os
+    import socket
+    import threading
+    from p2pfl_amd.controller import Controller
+    from p2pfl_amd.runtime.launch import run_scenario
+    from p2pfl_amd.learning.pytorch.datamodule import synthetic_classification
+    tx, ty, ex, ey = synthetic_classification(8000, 1600, 784, 10, seed=1234)     # a small shared MNIST-shaped set
+    monkeypatch.setattr(MNISTDataModule, "mnist_train", (tx, ty))
+    monkeypatch.setattr(MNISTDataModule, "mnist_val", (ex, ey))
+    cdir = os.path.join(str(tmp_path), "config", "scen")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    fast = fast_participant("DFL")
+    over = {k: fast[k] for k in fast if k.isupper()}
+    over["tracking_args"] = {"log_dir": str(tmp_path / "logs")}
+    Controller.generate_participants(cdir, 4, "DFL", "MNIST", "MLP", rounds=5, epochs=1, accelerator="cpu",
+                                     controller="", overrides=over)
+    for i in range(4):
+        path = os.path.join(cdir, f"participant_{i}.json")
+        p = json.load(open(path))
+        p["network_args"]["neighbors"] = " ".join(f"127.0.0.1:{45000 + j}" for j in ((i - 1) % 4, (i + 1) % 4))
+        p["scenario_args"]["name"] = "scen"
+        json.dump(p, open(path, "w"))
+    out = {}
+    t = threading.Thread(target=lambda: out.update(run_scenario(cdir, device="cpu", gateways=[f"0:{port}"],
+                                                                wait_start=60.0)), daemon=True)
+    t.start()
+    ext = external_node(39, Role.AGGREGATOR, "DFL")
+    try:
+        assert wait_for(lambda: _port_open(port), 60)
+        ext.connect_to("127.0.0.1", port, full=False)
+        assert wait_for(lambda: len(ext.get_neighbors()) == 1, 30)
+        ext.set_start_learning(rounds=2, epochs=1)
+        t.join(240)
+        assert not t.is_alive()
+    finally:
+        ext.stop()
+    assert out["rounds"] == 2 and out["nodes"] == 4
+    log0 = open(tmp_path / "logs" / "scen" / "participant_0.log").read()
+    assert "TCP gateway of virtual node 0" in log0 and "round 1 role" in log0
+    assert os.path.exists(tmp_path / "logs" / "scen" / "metrics" / "participant_2" / "metrics.csv")
+
+
+def _port_open(port):
+    import socket
+    s = socket.socket()
+    s.settimeout(0.2)
+    try:
+        s.connect(("127.0.0.1", port))
+        return True
+    except OSError:
+        return False
+    finally:
+        s.close()

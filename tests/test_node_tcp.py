@@ -228,3 +228,22 @@ def test_every_model_family_federates_over_tcp(dataset, model):
             assert sa["batchnorm1.num_batches_tracked"].shape == ()
     finally:
         stop_all(nodes)
+
+
+def test_handshake_line_does_not_swallow_the_next_message():
+    """A dialler may send START_LEARNING right behind its CONNECT line (one TCP segment): the accept path must
+    consume the handshake line only (the reference's recv(BLOCK_SIZE) drops what follows, base_node.py:229)."""
+    import socket
+    from p2pfl_amd.base_node import _recv_line
+    a, b = socket.socketpair()
+    try:
+        a.sendall(b"CONNECT 127.0.0.1 4711 0 0\nSTART_LEARNING 2 1\nMODEL_INITIALIZED\n")
+        assert _recv_line(b, 2048) == b"CONNECT 127.0.0.1 4711 0 0\n"
+        b.settimeout(2)
+        assert b.recv(2048) == b"START_LEARNING 2 1\nMODEL_INITIALIZED\n"
+        a.sendall(b"CONN")                      # a line that arrives in pieces
+        a.sendall(b"ECT h 1 1 1\nBEAT x\n")
+        assert _recv_line(b, 2048) == b"CONNECT h 1 1 1\n"
+    finally:
+        a.close()
+        b.close()

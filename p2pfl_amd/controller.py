@@ -277,7 +277,8 @@ class Controller:
             pc["device_args"]["idx"] = i
             pc["device_args"]["uid"] = hashlib.sha1(
                 (str(pc["network_args"]["ip"]) + str(pc["network_args"]["port"]) + str(self.scenario_name)).encode()).hexdigest()
-            pc["geo_args"]["latitude"], pc["geo_args"]["longitude"] = TopologyManager.get_coordinates(random_geo=True)
+            if not pc["geo_args"].get("fixed"):       # random in Spain / Switzerland (controller.py:263) unless the designer placed it
+                pc["geo_args"]["latitude"], pc["geo_args"]["longitude"] = TopologyManager.get_coordinates(random_geo=True)
             pc["tracking_args"]["log_dir"] = self.log_dir
             pc["tracking_args"]["config_dir"] = self.config_dir
             if pc["device_args"]["start"]:

@@ -68,6 +68,81 @@ def _scalar_summary(tag: str, value: float) -> bytes:
     return _field_bytes(1, val)
 
 
+# ---------------------------------------------------------------------------- reader (statistics page)
+def _read_varint(buf: bytes, pos: int):
+    n = shift = 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        n |= (b & 0x7F) << shift
+        shift += 7
+        if not b & 0x80:
+            return n, pos
+
+
+def _pb_fields(buf: bytes):
+    """(field number, wire type, value) of one protobuf message: varints as int, 64/32-bit as raw bytes, length-
+    delimited as bytes. Enough for Event / Summary / Summary.Value."""
+    pos, end = 0, len(buf)
+    while pos < end:
+        key, pos = _read_varint(buf, pos)
+        num, wt = key >> 3, key & 7
+        if wt == 0:
+            v, pos = _read_varint(buf, pos)
+        elif wt == 1:
+            v, pos = buf[pos:pos + 8], pos + 8
+        elif wt == 5:
+            v, pos = buf[pos:pos + 4], pos + 4
+        elif wt == 2:
+            ln, pos = _read_varint(buf, pos)
+            v, pos = buf[pos:pos + ln], pos + ln
+        else:
+            return
+        yield num, wt, v
+
+
+def read_event_file(path: str, check_crc: bool = True) -> Dict[str, list]:
+    """Scalars of one ``events.out.tfevents.*`` file as ``{tag: [[step, value], ...]}`` - written by this module, by
+    TensorBoard's SummaryWriter or by Lightning's TensorBoardLogger (the reference's logger,
+    fedstellar/learning/pytorch/statisticslogger.py:13-60): the record framing and the Event / Summary fields are
+    the same. A truncated tail (a run still writing) ends the read quietly; a CRC mismatch raises ValueError."""
+    out: Dict[str, list] = {}
+    with open(path, "rb") as f:
+        data = f.read()
+    pos = 0
+    while pos + 12 <= len(data):
+        header = data[pos:pos + 8]
+        (ln,) = struct.unpack("<Q", header)
+        if pos + 12 + ln + 4 > len(data):
+            break
+        if check_crc and struct.unpack("<I", data[pos + 8:pos + 12])[0] != _masked_crc(header):
+            raise ValueError(f"{path}: corrupt record header at byte {pos}")
+        rec = data[pos + 12:pos + 12 + ln]
+        if check_crc and struct.unpack("<I", data[pos + 12 + ln:pos + 16 + ln])[0] != _masked_crc(rec):
+            raise ValueError(f"{path}: corrupt record at byte {pos}")
+        pos += 16 + ln
+        step, summary = 0, None
+        for num, wt, v in _pb_fields(rec):
+            if num == 2 and wt == 0:
+                step = v
+            elif num == 5 and wt == 2:
+                summary = v
+        if summary is None:
+            continue
+        for num, wt, val in _pb_fields(summary):
+            if num != 1 or wt != 2:
+                continue
+            tag, x = None, None
+            for n2, w2, v2 in _pb_fields(val):
+                if n2 == 1 and w2 == 2:
+                    tag = v2.decode("utf-8", "replace")
+                elif n2 == 2 and w2 == 5:
+                    x = struct.unpack("<f", v2)[0]
+            if tag is not None and x is not None:
+                out.setdefault(tag, []).append([int(step), float(x)])
+    return out
+
+
 class _EventWriter:
     def __init__(self, logdir: str):
         os.makedirs(logdir, exist_ok=True)

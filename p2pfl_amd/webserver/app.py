@@ -283,6 +283,37 @@ def update_topology(scenario_name, nodes):
         app.logger.debug("topology update failed: %s", e)
 
 
+@app.route("/api/scenario/<scenario_name>/topology")
+def fedstellar_api_topology(scenario_name):
+    """Live topology as the reference's 3-D graph JSON (``TopologyManager.update_topology_3d_json``,
+    utils/topologymanager.py:321-354: nodes {uid,id,ipport,role,ip,port,start} + links {source,target,value}) built
+    from the nodes' last status reports, plus each node's coordinates and liveness for the map overlay. A copy is
+    kept as ``<config_dir>/<scenario>/topology.json`` like the reference's (commented-out) call at app.py:383."""
+    cdir = _under(app.config["config_dir"], scenario_name)
+    rows = _node_rows(scenario_name)
+    starts = {}
+    for path in glob.glob(os.path.join(cdir, "participant_*.json")):
+        try:
+            with open(path) as f:
+                pc = json.load(f)
+            starts[int(pc["device_args"]["idx"])] = bool(pc["device_args"].get("start"))
+        except (OSError, ValueError, KeyError, TypeError):
+            continue
+    participants = [{"device_args": {"uid": r["uid"], "idx": r["idx"], "role": r["role"], "start": starts.get(int(r["idx"]), False)},
+                     "network_args": {"ip": r["ip"], "port": r["port"], "neighbors": r["neighbors"] or ""}} for r in rows]
+    path = os.path.join(cdir, "topology.json")
+    data = {"nodes": [], "links": []}
+    if os.path.isdir(cdir):
+        TopologyManager.update_topology_3d_json(participants, path)
+        with open(path) as f:
+            data = json.load(f)
+    known = {n["ipport"] for n in data["nodes"]}
+    data["links"] = [l for l in data["links"] if l["target"] in known]
+    for n, r in zip(data["nodes"], rows):
+        n.update(latitude=r["latitude"], longitude=r["longitude"], status=r["status"], timestamp=r["timestamp"])
+    return jsonify(data)
+
+
 @app.route("/scenario/<scenario_name>/node/update", methods=["POST"])
 def fedstellar_update_node(scenario_name):
     """Status ingest from the nodes: the body is the node's live participant config."""
@@ -422,20 +453,38 @@ def fedstellar_remove_scenario(scenario_name):
 
 # ------------------------------------------------------------------ statistics
 def _read_metrics(scenario_name):
+    """Per participant ``{metric: [[step, value], ...]}`` from what the nodes' loggers left under
+    ``<log_dir>/<scenario>/metrics/participant_<i>/``: the ``metrics.csv`` of the CSV logger and the scalars of
+    every TensorBoard event file (the reference's only format, statisticslogger.py:13-60) - the page needs no
+    TensorBoard process. Where both carry a metric the event file wins (it is what TensorBoard would show)."""
+    from ..learning.pytorch.statisticslogger import read_event_file
     out = {}
-    for path in sorted(glob.glob(os.path.join(app.config["log_dir"], scenario_name, "metrics", "participant_*", "metrics.csv"))):
-        node = os.path.basename(os.path.dirname(path))
+    root = os.path.join(app.config["log_dir"], scenario_name, "metrics")
+    for pdir in sorted(glob.glob(os.path.join(root, "participant_*"))):
+        if not os.path.isdir(pdir):
+            continue
         series = {}
-        with open(path) as f:
-            next(f, None)
-            for line in f:
-                parts = line.rstrip("\n").split(",")
-                if len(parts) == 4:
-                    try:
-                        series.setdefault(parts[2], []).append([int(parts[1]), float(parts[3])])
-                    except ValueError:
-                        continue
-        out[node] = series
+        path = os.path.join(pdir, "metrics.csv")
+        if os.path.exists(path):
+            with open(path) as f:
+                next(f, None)
+                for line in f:
+                    parts = line.rstrip("\n").split(",")
+                    if len(parts) == 4:
+                        try:
+                            series.setdefault(parts[2], []).append([int(parts[1]), float(parts[3])])
+                        except ValueError:
+                            continue
+        events = {}
+        for ev in sorted(glob.glob(os.path.join(pdir, "**", "events.out.tfevents.*"), recursive=True)):
+            try:
+                for tag, pts in read_event_file(ev).items():
+                    events.setdefault(tag, []).extend(pts)
+            except (OSError, ValueError, IndexError) as e:
+                app.logger.debug("skipping %s: %s", ev, e)
+        for tag, pts in events.items():
+            series[tag] = sorted(pts)
+        out[os.path.basename(pdir)] = series
     return out
 
 
@@ -490,7 +539,25 @@ def _controller_args(data, scenario_name):
         config=app.config["config_dir"], logs=app.config["log_dir"], env=None, python=app.config["python_path"],
         matrix=data.get("matrix"), engine=data.get("engine", "auto"), gpus=data.get("gpus"),
         encrypt=bool(data.get("encrypt", False)), network_subnet=data.get("network_subnet"),
-        network_gateway=data.get("network_gateway"))
+        network_gateway=data.get("network_gateway"), control_plane=bool(data.get("control_plane", False)),
+        gateway=[str(g) for g in (data.get("gateways") or []) if re.fullmatch(r"\d+(:\d+)?", str(g))])
+
+
+_SHAPING = {"interface": r"[A-Za-z0-9_.:\-]{1,15}", "rate": r"\d+(\.\d+)?[KMG]?bps", "loss": r"\d+(\.\d+)?%",
+            "delay": r"\d+(\.\d+)?(us|ms|s)", "delay-distro": r"\d+(\.\d+)?"}
+
+
+def _shaping_fields(nd: dict) -> dict:
+    """The network-shaping keys of one designer node (they end up on a ``tcset`` command line: strict formats)."""
+    out = {}
+    for key, pattern in _SHAPING.items():
+        v = nd.get(key, nd.get(key.replace("-", "_")))
+        if v in (None, ""):
+            continue
+        if not re.fullmatch(pattern, str(v)):
+            raise ValueError(f"bad {key} {v!r}")
+        out[key] = float(v) if key == "delay-distro" else str(v)
+    return out
 
 
 @app.route("/scenario/deployment/run", methods=["POST"])
@@ -529,6 +596,16 @@ def fedstellar_scenario_deployment_run():
                                 start=bool(nd.get("start")) if have_start else i == 0,
                                 accelerator=data.get("accelerator", "auto"))
         p["network_args"].update(ip=nd.get("ip", "127.0.0.1"), ipdemo=nd.get("ipdemo", ""), port=int(nd.get("port", 45000 + i)))
+        # WAN emulation of a physical deployment (tcset in BaseNode, reference base_node.py:82-85) and the map position
+        try:
+            p["network_args"].update(_shaping_fields(nd))
+            if nd.get("latitude") not in (None, "") and nd.get("longitude") not in (None, ""):
+                lat, lon = float(nd["latitude"]), float(nd["longitude"])
+                if not (-90 <= lat <= 90 and -180 <= lon <= 180):
+                    raise ValueError("coordinates out of range")
+                p["geo_args"].update(latitude=str(lat), longitude=str(lon), fixed=True)
+        except ValueError as e:
+            return jsonify({"error": f"node {i}: {e}"}), 400
         p["data_args"]["dataset"] = data.get("dataset", "MNIST")
         p["model_args"]["model"] = data.get("model", "MLP")
         p["training_args"]["epochs"] = int(data.get("epochs", 3))

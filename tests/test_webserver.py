@@ -256,3 +256,78 @@ def test_remove_refuses_dot_names_and_keeps_the_roots(web):
     assert (tmp / "config" / "keep").is_dir() and (tmp / "logs" / "keep").is_dir()
     Controller.remove_files_by_scenario("keep")
     assert not (tmp / "config" / "keep").exists() and (tmp / "config").is_dir()
+
+
+def test_designer_node_fields_topology_json_and_event_file_statistics(web, monkeypatch):
+    """Per-node network shaping / coordinates from the designer land in the participant files (validated: they end
+    up on a tcset command line); the live topology comes back in the reference's topology.json shape with
+    coordinates; the statistics page reads TensorBoard event files without TensorBoard."""
+    appmod, c, tmp = web
+    started = {}
+    monkeypatch.setattr(appmod.Controller, "start_nodes_cmd", lambda self, idx: started.update(mode="cmd"))
+    monkeypatch.setattr(appmod.Controller, "start_nodes_batched",
+                        lambda self: started.update(mode="batched", cp=self.control_plane, gw=self.gateways))
+    monkeypatch.setattr(appmod.Controller, "killdockers", staticmethod(lambda: None))
+    nodes = {str(i): {"id": i, "ip": "127.0.0.1", "ipdemo": "", "port": 47100 + i, "role": "aggregator", "start": i == 0,
+                      "interface": "eth1", "rate": "10Mbps", "loss": "0.5%", "delay": "20ms", "delay_distro": "5",
+                      "latitude": "46.5", "longitude": str(7.0 + i)} for i in range(3)}
+    body = {"scenario_title": "T", "scenario_description": "D", "n_nodes": 3, "federation": "DFL", "topology": "fully",
+            "matrix": None, "simulation": True, "docker": False, "rounds": 1, "epochs": 1, "dataset": "MNIST", "model": "MLP",
+            "accelerator": "cpu", "engine": "batched", "control_plane": True, "gateways": ["0:47500", "bad;rm"],
+            "nodes": nodes}
+    _login(c)
+    bad = json.loads(json.dumps(body))
+    bad["nodes"]["1"]["rate"] = "10Mbps; reboot"
+    r = c.post("/scenario/deployment/run", data=json.dumps(bad), content_type="application/json")
+    assert r.status_code == 400 and "node 1" in r.get_json()["error"]
+    r = c.post("/scenario/deployment/run", data=json.dumps(body), content_type="application/json")
+    assert r.status_code == 200, r.data
+    name = r.get_json()["scenario_name"]
+    assert started == {"mode": "batched", "cp": True, "gw": ["0:47500"]}
+    p2 = json.loads((tmp / "config" / name / "participant_2.json").read_text())
+    na = p2["network_args"]
+    assert (na["interface"], na["rate"], na["loss"], na["delay"], na["delay-distro"]) == ("eth1", "10Mbps", "0.5%", "20ms", 5.0)
+    assert float(p2["geo_args"]["latitude"]) == 46.5 and float(p2["geo_args"]["longitude"]) == 9.0
+    # nodes report in -> topology.json
+    tok = {"X-Scenario-Token": (tmp / "config" / name / ".token").read_text()}
+    for i in range(3):
+        cfg = json.loads((tmp / "config" / name / f"participant_{i}.json").read_text())
+        assert c.post(f"/scenario/{name}/node/update", data=json.dumps(cfg), content_type="application/json",
+                      headers=tok).status_code == 200
+    t = c.get(f"/api/scenario/{name}/topology").get_json()
+    assert [n["ipport"] for n in t["nodes"]] == [f"127.0.0.1:{47100 + i}" for i in range(3)]
+    assert t["nodes"][0]["start"] is True and t["nodes"][1]["role"] == "aggregator" and t["nodes"][2]["status"] is True
+    assert float(t["nodes"][2]["longitude"]) == 9.0
+    assert len(t["links"]) == 6 and {"source": "127.0.0.1:47100", "target": "127.0.0.1:47101", "value": 1} in t["links"]
+    assert json.loads((tmp / "config" / name / "topology.json").read_text())["links"]
+    assert c.get("/api/scenario/../topology").status_code in (400, 404)
+    # event files only (no metrics.csv): the statistics API still has the scalars
+    from p2pfl_amd.learning.pytorch.statisticslogger import FedstellarLogger
+    lg = FedstellarLogger(str(tmp / "logs" / name), name="metrics", version="participant_1")
+    lg.log_metrics_direct({"Train/Loss": 0.5, "TestEpoch/Accuracy": 0.75}, 0)
+    lg.log_metrics_direct({"Train/Loss": 0.25}, 1)
+    lg.finalize()
+    m = c.get(f"/api/scenario/{name}/statistics/").get_json()
+    assert m["participant_1"]["Train/Loss"] == [[0, 0.5], [1, 0.25]] and m["participant_1"]["TestEpoch/Accuracy"] == [[0, 0.75]]
+    page = c.get(f"/scenario/{name}/statistics/")
+    assert page.status_code == 200 and b"Train/Loss" in page.data
+    assert c.get(f"/scenario/{name}/monitoring").status_code == 200
+    assert b"Role presets" in c.get("/scenario/deployment/").data
+
+
+def test_event_file_reader_rejects_corruption(tmp_path):
+    from p2pfl_amd.learning.pytorch.statisticslogger import FedstellarLogger, read_event_file
+    import glob
+    lg = FedstellarLogger(str(tmp_path), name="metrics", version="participant_0")
+    for s in range(5):
+        lg.log_metrics_direct({"a/b": float(s)}, s)
+    lg.finalize()
+    path = glob.glob(str(tmp_path / "metrics" / "participant_0" / "events.out.tfevents.*"))[0]
+    assert read_event_file(path) == {"a/b": [[s, float(s)] for s in range(5)]}
+    raw = bytearray(open(path, "rb").read())
+    open(path, "wb").write(raw[:-7])                       # a run still writing: the torn tail is ignored
+    assert len(read_event_file(path)["a/b"]) == 4
+    raw[40] ^= 0xFF
+    open(path, "wb").write(raw)
+    with pytest.raises(ValueError):
+        read_event_file(path)

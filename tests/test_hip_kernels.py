@@ -310,6 +310,71 @@ def test_conv2_wgrad_dgrad(ks, B, K, prec, cores):
         assert rel_err(da1[k], ref_x) < TOL_CONV[prec]
 
 
+def _conv_fuzz_case(K, B, ks, precision, F1):
+    """Both conv stages, forward and backward, for one (clients, batch, kernel size) against torch."""
+    h = hip()
+    Cin, Cout = 32, 64
+    tol = TOL_CONV[precision]
+    ks1 = 5 if ks == 5 else 7               # MNIST CNN: 5x5 / 5x5, FEMNIST CNN: 7x7 / 3x3
+    # stage 1 (C_in = 1) with an index gather like the engine's
+    n = B + 3
+    data = torch.randn(K, n, 784, device=DEV)
+    sidx = torch.stack([torch.randperm(n, device=DEV)[:B] for _ in range(K)]).to(torch.int32)
+    w1 = slab_view(K, (F1, ks1 * ks1)) * 0.2
+    b1 = slab_view(K, (F1,)) * 0.1
+    a1 = torch.empty(K, B, F1, 196, device=DEV)
+    code1 = torch.empty(K, B, F1, 196, dtype=torch.uint8, device=DEV)
+    h.conv1_fwd(data, sidx, w1, b1, a1, code1, ks1, prec=precision)
+    g1 = torch.randn(K, B, F1, 196, device=DEV)
+    dw1, db1 = slab_view(K, (F1, ks1 * ks1)), slab_view(K, (F1,))
+    h.conv1_wgrad(g1, code1, data, sidx, dw1, db1, ks1, prec=precision)
+    # stage 2
+    x2 = torch.randn(K, B, Cin, 196, device=DEV).relu()
+    w2 = slab_view(K, (Cout, Cin * ks * ks)) * 0.05
+    b2 = slab_view(K, (Cout,)) * 0.1
+    a2 = torch.empty(K, B, Cout, 49, device=DEV)
+    code2 = torch.empty(K, B, Cout, 49, dtype=torch.uint8, device=DEV)
+    h.conv2_fwd(x2, w2, b2, a2, code2, ks, prec=precision)
+    g2 = torch.randn(K, B, Cout, 49, device=DEV)
+    dw2, db2 = slab_view(K, (Cout, Cin * ks * ks)), slab_view(K, (Cout,))
+    da1 = torch.empty(K, B, Cin, 196, device=DEV)
+    h.conv2_wgrad(g2, code2, x2, dw2, db2, ks, prec=precision)
+    h.conv2_dgrad(g2, code2, w2, da1, ks, prec=precision)
+    dpre1, dpre2 = route(g1, code1, 14), route(g2, code2, 7)
+    for k in sorted({0, K - 1, K // 2}):
+        xb = data[k][sidx[k].long()].view(B, 1, 28, 28)
+        ref = F.max_pool2d(F.conv2d(xb, w1[k].reshape(F1, 1, ks1, ks1), b1[k], padding=ks1 // 2).relu(), 2, 2)
+        assert rel_err(a1[k], ref.reshape(B, F1, 196)) < tol
+        ref = torch.nn.grad.conv2d_weight(xb, (F1, 1, ks1, ks1), dpre1[k], padding=ks1 // 2).reshape(F1, ks1 * ks1)
+        assert rel_err(dw1[k], ref) < tol and rel_err(db1[k], dpre1[k].sum(dim=(0, 2, 3))) < tol
+        x = x2[k].view(B, Cin, 14, 14)
+        wk = w2[k].reshape(Cout, Cin, ks, ks)
+        ref = F.max_pool2d(F.conv2d(x, wk, b2[k], padding=ks // 2).relu(), 2, 2).reshape(B, Cout, 49)
+        assert rel_err(a2[k], ref) < tol
+        assert rel_err(dw2[k], torch.nn.grad.conv2d_weight(x, wk.shape, dpre2[k], padding=ks // 2).reshape(Cout, -1)) < tol
+        assert rel_err(db2[k], dpre2[k].sum(dim=(0, 2, 3))) < tol
+        assert rel_err(da1[k], torch.nn.grad.conv2d_input(x.shape, wk, dpre2[k], padding=ks // 2).reshape(B, Cin, 196)) < tol
+
+
+def test_conv_shapes_fuzz():
+    """Property test over the launch geometry: client counts that are not multiples of the 8 XCDs, odd batch sizes
+    (the forward kernels pair samples), batches smaller than the batch-split counts, both kernel sizes, every
+    precision policy. One process, bounded examples; every launcher validates its shapes on the host first."""
+    hypothesis = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=14, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(K=st.integers(1, 19), B=st.integers(1, 37), ks=st.sampled_from([3, 5]),
+           precision=st.sampled_from(["fp32", "fp32-split", "bf16"]), F1=st.sampled_from([32]))
+    def run(K, B, ks, precision, F1):
+        _conv_fuzz_case(K, B, ks, precision, F1)
+
+    run()
+    for K, B, ks in ((9, 1, 5), (17, 3, 3), (1, 33, 5)):            # corners, always
+        for precision in ("fp32", "fp32-split", "bf16"):
+            _conv_fuzz_case(K, B, ks, precision, 32)
+
+
 @pytest.mark.parametrize("ks", [5, 3])
 def test_conv2_split_is_fp32_accurate(ks):
     """The three-term bf16 split (fp32-split) against a float64 oracle: its error must be in the class of the fp32

@@ -2,7 +2,8 @@
 
 Re-floods hashed control messages (BEAT / ROLE / START_LEARNING / ...) to the neighbours that have
 not seen them yet: every ``1 / GOSSIP_MESSAGES_FREC`` seconds at most ``GOSSIP_MESSAGES_PER_ROUND``
-(message, peer-set) pairs leave through ``GOSSIP_BROADCAST_EVENT (msg, exclude_list)``.
+sends - (message, peer) pairs, as in the reference - leave through ``GOSSIP_BROADCAST_EVENT (msg, exclude_list)``;
+a message that does not fit completely is delivered to the peers that do and keeps the rest for the next tick.
 The thread sleeps on a condition variable while the queue is empty instead of spinning at 100 Hz.
 """
 from __future__ import annotations
@@ -47,18 +48,31 @@ class Gossiper(threading.Thread, Observable):
             with self._cv:
                 if not self._pending:
                     self._cv.wait(timeout=0.5)
-                batch = []
-                budget = budget_per_round
-                while self._pending and budget > 0:
-                    batch.append(self._pending.popleft())
-                    budget -= 1
-            if batch:
-                neighbors = self._current_neighbors()
-                for msg, have in batch:
-                    # exclude the peers the message came from; the broadcast skips them
-                    names = {h if isinstance(h, str) else h.get_name() for h in have}
-                    excl = [nc for nc in neighbors if nc.get_name() in names]
+                pending = list(self._pending)
+                self._pending.clear()
+            # the budget counts SENDS, i.e. (message, peer) pairs (gossiper.py:84-103): a message whose remaining
+            # peers do not fit goes to as many as do and waits for the next tick with the rest
+            budget = budget_per_round
+            neighbors = self._current_neighbors() if pending else []
+            keep = []
+            for k, (msg, have) in enumerate(pending):
+                if budget <= 0:
+                    keep.extend(pending[k:])
+                    break
+                names = {h if isinstance(h, str) else h.get_name() for h in have}
+                todo = [nc for nc in neighbors if nc.get_name() not in names]
+                excl = [nc for nc in neighbors if nc.get_name() in names]
+                if len(todo) > budget:
+                    later = todo[budget:]
+                    self.notify(Events.GOSSIP_BROADCAST_EVENT, (msg, excl + later))
+                    keep.append((msg, list(have) + [nc.get_name() for nc in todo[:budget]]))
+                    budget = 0
+                else:
                     self.notify(Events.GOSSIP_BROADCAST_EVENT, (msg, excl))
+                    budget -= len(todo)
+            if keep:
+                with self._cv:
+                    self._pending.extendleft(reversed(keep))
             sleep = period - (time.time() - begin)
             if sleep > 0 and not self._terminate.is_set():
                 time.sleep(sleep)

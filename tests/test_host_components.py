@@ -133,12 +133,21 @@ def test_gossiper_budget_and_exclusion():
     g.add_observer(Sink())
     g.add_messages([b"m1", b"m2", b"m3", b"m4", b"m5"], ncs[0])
     g.start()
-    time.sleep(0.08)                         # ~2 ticks of 50 ms with a budget of 2 each
+    time.sleep(0.08)                         # ~2 ticks of 50 ms; a budget of 2 SENDS = one message to its two peers
     n_early = len(sent)
+    time.sleep(0.4)
+    g.stop()
+    assert 1 <= n_early <= 3 and len(sent) == 5
+    assert all(e == Events.GOSSIP_BROADCAST_EVENT and excl == ["a"] for e, _, excl in sent)
+    # a message that does not fit goes to the peers that do and keeps the rest for the next tick (gossiper.py:95-103)
+    sent.clear()
+    g = Gossiper("me", lambda: ncs, Config(participant={"GOSSIP_MESSAGES_FREC": 20, "GOSSIP_MESSAGES_PER_ROUND": 3}))
+    g.add_observer(Sink())
+    g.add_messages([b"m1", b"m2"], ncs[0])
+    g.start()
     time.sleep(0.3)
     g.stop()
-    assert 2 <= n_early <= 4 and len(sent) == 5
-    assert all(e == Events.GOSSIP_BROADCAST_EVENT and excl == ["a"] for e, _, excl in sent)
+    assert [(m, sorted(x)) for _, m, x in sent] == [(b"m1", ["a"]), (b"m2", ["a", "c"]), (b"m2", ["a", "b"])]
 
 
 # ---------------------------------------------------------------- codec

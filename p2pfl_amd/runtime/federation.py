@@ -189,7 +189,11 @@ class BatchedFederation:
             if self._present(i) and Role.waits(self.roles[i]):
                 aggs = [j for j in self.neighbors(i) if self._present(j) and j in train_sets]
                 if aggs:
-                    adopt[i] = aggs[0]
+                    # "the first aggregated model that arrives" (node.py:526-531) on the virtual clock: an
+                    # aggregator that waits out AGGREGATION_TIMEOUT for a missing member answers last, otherwise
+                    # the one that collects the fewest models is done first; the node index breaks ties
+                    late = set(self.timed_out)
+                    adopt[i] = min(aggs, key=lambda j: (j in late, len(train_sets[j]), j))
         return train_sets, adopt
 
     def _structure_key(self) -> bytes:

@@ -290,3 +290,23 @@ def test_out_of_range_labels_are_refused():
     with pytest.raises(ValueError):
         eng.set_data(tx, bad, vx, vy, ex, ey)
     eng.set_data(tx, ty, vx, vy, ex, ey)
+
+
+def test_waiting_node_adopts_the_aggregator_that_finishes_first():
+    """node.py:526-531: a trainer takes the first aggregated model that reaches it. On the virtual clock that is the
+    neighbouring aggregator with the fewest models to collect - and never one that is sitting out
+    AGGREGATION_TIMEOUT for a dead member while another neighbour is already done."""
+    # line 0 - 1 - 2 - 3 - 4 with a trainer in the middle: aggregator 1 collects {0, 1, 2}, aggregator 3 {2, 3, 4}
+    adj = np.zeros((5, 5), dtype=np.int64)
+    for a, b in ((0, 1), (1, 2), (2, 3), (3, 4)):
+        adj[a, b] = adj[b, a] = 1
+    roles = [Role.AGGREGATOR, Role.AGGREGATOR, Role.TRAINER, Role.AGGREGATOR, Role.AGGREGATOR]
+    fed = BatchedFederation(SPEC, adj, roles=roles, device="cpu", engine="eager", epochs=1, seed=5,
+                            instant_detection=False, node_timeout=20.0, aggregation_timeout=60.0)
+    fed.init_params()
+    fed.set_local_data(*synthetic_shards(5, 32, 8, 16, 10, seed=1))
+    _, adopt = fed._round_structure()
+    assert adopt == {2: 1}                                # equal sizes: the index breaks the tie
+    fed.alive[0] = False                                  # dead but not yet evicted: 1 waits for a model that never comes
+    _, adopt = fed._round_structure()
+    assert fed.timed_out == [1] and adopt == {2: 3}

@@ -383,6 +383,153 @@ void linear_wgrad_adam_kernel(WgradAdamArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Fused update that also produces the layer's DATA gradient (fp32): one pass over the weights less per step.
+//
+//   dX[b][n] = sum_m dY[b][m] * W[m][n]
+//
+// reads the same W the Adam epilogue is about to read. The epilogue holds W in accumulator layout - lane l,
+// register e = W[row (e&3) + 8(e>>2) + 4(l>>5)][4 (l&31) + j] for the four column tiles j - and that IS a valid B
+// operand of v_mfma_f32_32x32x2_f32 for the k pair (row, row + 4): the order inside a reduction is free as long as
+// both operands agree, so the A operand is dY[b = l & 31][that same row], one dword from the dY tile already in LDS.
+// The weights go from the load that Adam needs straight into the matrix cores; no data moves.
+// To keep the reduction over m inside one workgroup a block owns a 128-column strip over ALL rows (16 row tiles
+// for 2048 outputs; the X tile is staged once, dY tiles are double-buffered), the four waves' partial sums are
+// added through LDS in a fixed order (bitwise reproducible), and dX leaves as 512-byte rows.
+// Cost: 64 more MFMAs per wave and row tile (as many as the weight gradient itself) in a kernel whose matrix cores
+// idle 91 % of the time; saved: the separate data-gradient kernel's pass over the weights (2.6 GB for 100 clients).
+// ---------------------------------------------------------------------------------------
+template <bool FRESH>
+__global__ __launch_bounds__(256, 2)
+void linear_wgrad_adam_dgrad_kernel(WgradAdamArgs a, float* dx_all, long dx_cs) {
+    constexpr int BK = GEMM_BK, LDK = BK + lds_pad<float>();
+    __shared__ __attribute__((aligned(16))) float sa[2][128 * LDK];
+    __shared__ __attribute__((aligned(16))) float sb[128 * LDK];
+    const int c = blockIdx.y, n0 = blockIdx.x * 128;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 31, h = lane >> 5;
+    LoadColMajorK al{a.dy + c * a.dy_cs, a.Out, a.B, a.Out};
+    LoadXTOnes bl{a.x + c * a.x_cs, a.In, a.B, a.sidx ? a.sidx + c * a.s_cs : nullptr};
+    const float ib1 = a.h.bc ? a.h.bc[0] : a.h.inv_bc1;
+    const float isb2 = a.h.bc ? a.h.bc[1] : a.h.inv_sqrt_bc2;
+    const long wo = c * a.w_cs, bo = c * a.b_cs;
+    const EpiWgradAdam<FRESH> epi{a.w + wo, a.mw + wo, a.vw + wo, a.b + bo, a.mb + bo, a.vb + bo, a.Out, a.In,
+                                  a.h.lr * ib1, a.h.beta1, a.h.beta2, a.h.eps, a.h.weight_decay, isb2};
+    const int M = a.Out, N = a.In;
+
+    TileStager<128, 256, LoadColMajorK, false, BK, float> sta;
+    {
+        TileStager<128, 256, LoadXTOnes, true, BK, float> stb;
+        stb.load(bl, n0, 0);
+        stb.store(sb);
+    }
+    sta.load(al, 0, 0);
+    sta.store(sa[0]);
+    __syncthreads();
+
+    f32x16 accx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accx[j][e] = 0.f;
+
+    const int MT = (M + 127) / 128;
+    const int n = n0 + 4 * r;
+    int cur = 0;
+#pragma unroll 1
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m0 = mt * 128;
+        f32x16 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        const float* as = sa[cur] + (wave * 32 + r) * LDK + h * 4;
+        const float* bs = sb + r * LDK + h * 4;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            const f32x4 af = *reinterpret_cast<const f32x4*>(as + kk * 8);
+            f32x4 bfr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bfr[j][e], acc[j], 0, 0, 0);
+        }
+        if (mt + 1 < MT) sta.load(al, m0 + 128, 0);
+
+        // epilogue: Adam on the 32 x 128 piece of this wave, the weights feeding the data gradient on the way
+        const float* dyt = sa[cur] + (wave * 32) * LDK + r;          // dY[b = r][row] = dyt[row * LDK]
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int mloc = mfma_row(e, lane);
+            const int m = m0 + wave * 32 + mloc;
+            const bool vec = m < M && n + 3 < N;
+            const size_t o = (size_t)m * N + n;
+            f32x4 pv = {0.f, 0.f, 0.f, 0.f}, mv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (vec) {
+                pv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(epi.w + o));
+                if constexpr (!FRESH) {
+                    mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(epi.mw + o));
+                    vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(epi.vw + o));
+                }
+            } else if (m < M) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (n + j < N) pv[j] = epi.w[o + j];
+            }
+            const float ae = dyt[mloc * LDK];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) accx[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, pv[j], accx[j], 0, 0, 0);
+            if (vec) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float gr = acc[j][e] + epi.wd * pv[j];
+                    mv[j] = epi.beta1 * mv[j] + (1.f - epi.beta1) * gr;
+                    vv[j] = epi.beta2 * vv[j] + (1.f - epi.beta2) * gr * gr;
+                    pv[j] -= epi.step * (mv[j] / (sqrtf(vv[j]) * epi.isb2 + epi.eps));
+                }
+                __builtin_nontemporal_store(pv, reinterpret_cast<f32x4*>(epi.w + o));
+                __builtin_nontemporal_store(mv, reinterpret_cast<f32x4*>(epi.mw + o));
+                __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(epi.vw + o));
+            } else if (m < M && n <= N) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (n + j < N) epi.upd(epi.w + o + j, epi.mw + o + j, epi.vw + o + j, acc[j][e]);
+                    else if (n + j == N) epi.upd(epi.b + m, epi.mb + m, epi.vb + m, acc[j][e]);
+                }
+            }
+        }
+        if (mt + 1 < MT) sta.store(sa[cur ^ 1]);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // dX strip = sum of the four waves' partials, in wave order
+    float* red = sa[0];                     // [32 b][128 n]; the loop's last barrier freed both dY buffers
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float* q = red + mfma_row(e, lane) * 128 + 4 * r + j;
+                    *q = (w == 0 ? 0.f : *q) + accx[j][e];
+                }
+        }
+        __syncthreads();
+    }
+    float* dx = dx_all + c * dx_cs;
+    for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+        const int b = i >> 5, q = i & 31;
+        if (b < a.B && n0 + 4 * q + 3 < N)
+            *reinterpret_cast<f32x4*>(dx + (size_t)b * N + n0 + 4 * q) = *reinterpret_cast<const f32x4*>(red + b * 128 + 4 * q);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Weight gradient fused with the SGD-momentum update (the FEMNIST models): same idea, 4 words per weight
 // instead of 7 (gradient write + read and the separate pass over p / buf go away).
 // ---------------------------------------------------------------------------------------
@@ -494,6 +641,29 @@ P2PFL_API int p2pfl_linear_wgrad_adam(const float* dy, long dy_cs, const float* 
         if (fresh) hipLaunchKernelGGL((linear_wgrad_adam_kernel<4, 1, true, 0, __bf16>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((linear_wgrad_adam_kernel<4, 1, false, 0, __bf16>), grid, dim3(256), 0, stream, a);
     }
+    P2PFL_RETURN_LAST_ERROR();
+}
+
+// Fused update + data gradient (fp32 policies; see linear_wgrad_adam_dgrad_kernel). Returns -4 when the shape is
+// outside what the kernel covers (the caller then runs linear_dgrad + linear_wgrad_adam): B <= 32, In % 4 == 0,
+// 16-byte aligned weight / dx rows.
+P2PFL_API int p2pfl_linear_wgrad_adam_dgrad(const float* dy, long dy_cs, const float* x, long x_cs, float* w,
+                                            float* mw, float* vw, long w_cs, float* b, float* mb, float* vb,
+                                            long b_cs, float* dx, long dx_cs, int K, int B, int In, int Out, float lr,
+                                            float beta1, float beta2, float eps, float weight_decay, int t,
+                                            const float* bc, int fresh, const int* sidx, long s_cs, int prec,
+                                            hipStream_t stream) {
+    if (K <= 0 || B <= 0 || In <= 0 || Out <= 0 || t <= 0) return -1;
+    if (prec == PREC_BF16 || B > GEMM_BK || (In & 3) || (w_cs & 3) || (dx_cs & 3) || ((uintptr_t)w & 15) ||
+        ((uintptr_t)mw & 15) || ((uintptr_t)vw & 15) || ((uintptr_t)dx & 15) || K > 65535)
+        return -4;
+    const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
+    WgradAdamArgs a{dy, dy_cs, x, x_cs, w, mw, vw, w_cs, b, mb, vb, b_cs, B, In, Out,
+                    AdamHyper{lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
+                              (float)(1.0 / sqrt(bc2)), bc, fresh}, sidx, s_cs, 0};
+    const dim3 grid(cdiv(In + 1, 128), K);
+    if (fresh) hipLaunchKernelGGL(linear_wgrad_adam_dgrad_kernel<true>, grid, dim3(256), 0, stream, a, dx, dx_cs);
+    else hipLaunchKernelGGL(linear_wgrad_adam_dgrad_kernel<false>, grid, dim3(256), 0, stream, a, dx, dx_cs);
     P2PFL_RETURN_LAST_ERROR();
 }
 

@@ -49,14 +49,16 @@ def available() -> bool:
 
 P, L, I, F = c_void_p, c_long, c_int, c_float
 
-# Precision policy of the matrix products (see csrc/common.h): "fp32" keeps the operands in fp32
-# (v_mfma_f32_32x32x2_f32, exact fp32 fma chains - the reference trains 32-bit,
-# fedstellar/learning/pytorch/lightninglearner.py:182-193), "bf16" rounds them to bf16 with fp32 accumulation
-# (16x the matrix-core rate; a labelled fast mode). "fp32-split" is "fp32" except for the stage-2 convolutions (the
-# MFMA-bound kernels of a step), which form every fp32 product from three bf16 terms per operand - an exact
-# decomposition, six bf16 MFMAs with fp32 accumulation, error <= 2^-24 of the product, 2.7x fewer matrix-core
-# cycles. Every product wrapper takes ``prec`` (name or None = default).
-PRECISIONS = {"bf16": 0, "fp32": 1, "fp32-split": 2}
+# Precision policy of the matrix products (see csrc/common.h). The reference trains 32-bit
+# (fedstellar/learning/pytorch/lightninglearner.py:182-193), so the default is "fp32": fp32 storage, fp32 accumulation,
+# fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32 fma chains) everywhere except the stage-2 convolutions (the
+# matrix-core-bound kernels of a step), which form every fp32 product from three bf16 terms per operand - an EXACT
+# decomposition (3 x 8 significand bits), six bf16 MFMAs with fp32 accumulation, dropped cross terms <= 2^-24 of the
+# product: the same accuracy against a float64 oracle as the fp32 MFMA kernels at 2.7x fewer matrix-core cycles.
+# "fp32-mfma" runs those convolutions on v_mfma_f32_32x32x2_f32 too (nothing but fp32 instructions anywhere);
+# "bf16" rounds all operands to bf16 with fp32 accumulation (16x the matrix-core rate; a labelled fast mode).
+# Every product wrapper takes ``prec`` (name or None = default).
+PRECISIONS = {"bf16": 0, "fp32-mfma": 1, "fp32": 2}
 SPLIT_TERMS = 3
 _default_prec = "fp32"
 
@@ -73,7 +75,8 @@ def default_precision() -> str:
 
 
 _PRODUCT_OPS = frozenset((
-    "linear_fwd", "linear_dgrad", "linear_wgrad", "linear_wgrad_adam", "linear_wgrad_sgdm", "conv1_fwd", "conv1_wgrad",
+    "linear_fwd", "linear_dgrad", "linear_wgrad", "linear_wgrad_adam", "linear_wgrad_adam_dgrad", "linear_wgrad_sgdm",
+    "conv1_fwd", "conv1_wgrad",
     "conv2_prep_alloc", "conv2_prep", "conv2_fwd", "conv2_wgrad_scratch", "conv2_wgrad", "conv2_dgrad"))
 
 
@@ -116,6 +119,7 @@ class _Sig:
     p2pfl_linear_dgrad = [P, L, P, L, P, L, P, L, I, I, I, I, I, P]
     p2pfl_linear_wgrad = [P, L, P, L, P, L, P, L, I, I, I, I, P, L, I, P]
     p2pfl_linear_wgrad_adam = [P, L, P, L, P, P, P, L, P, P, P, L, I, I, I, I, F, F, F, F, F, I, P, I, P, L, I, P]
+    p2pfl_linear_wgrad_adam_dgrad = [P, L, P, L, P, P, P, L, P, P, P, L, P, L, I, I, I, I, F, F, F, F, F, I, P, I, P, L, I, P]
     p2pfl_linear_wgrad_sgdm = [P, L, P, L, P, P, L, P, P, L, I, I, I, I, F, F, F, I, P, L, I, P]
     p2pfl_conv1_fwd = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, P]
     p2pfl_conv1_wgrad = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, P]
@@ -239,6 +243,29 @@ def linear_wgrad_adam(dy, x, w, mw, vw, b, mb, vb, *, lr, beta1=0.9, beta2=0.999
                                         _stream()), "linear_wgrad_adam")
 
 
+def linear_wgrad_adam_dgrad(dy, x, w, mw, vw, b, mb, vb, dx, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
+                            t: int, bc=None, fresh: bool = False, sidx=None, prec=None) -> bool:
+    """:func:`linear_wgrad_adam` that also writes the layer's data gradient ``dx = dy @ w`` ([K,B,In], no mask) from
+    the weights it reads anyway - one pass over the weights less than ``linear_dgrad`` + ``linear_wgrad_adam``.
+    fp32 policies only. Returns False (nothing launched) when the shape is not covered: run the two kernels then."""
+    K, B, Out = dy.shape
+    In = x.shape[2]
+    assert w.shape == (K, Out, In) and b.shape == (K, Out) and dx.shape == (K, B, In)
+    assert w.stride(0) == mw.stride(0) == vw.stride(0) and b.stride(0) == mb.stride(0) == vb.stride(0)
+    if _prec(prec) == PRECISIONS["bf16"]:
+        return False
+    (dp, ds), (xp, xs), (sp, ss), (gp, gs) = _pc(dy), _pc(x), _pc(sidx, torch.int32), _pc(dx)
+    rc = load().p2pfl_linear_wgrad_adam_dgrad(dp, ds, xp, xs, _t(w).data_ptr(), _t(mw).data_ptr(), _t(vw).data_ptr(),
+                                              w.stride(0), _t(b).data_ptr(), _t(mb).data_ptr(), _t(vb).data_ptr(),
+                                              b.stride(0), gp, gs, K, B, In, Out, lr, beta1, beta2, eps, weight_decay, t,
+                                              None if bc is None else _t(bc).data_ptr(), int(fresh), sp, ss,
+                                              _prec(prec), _stream())
+    if rc == -4:
+        return False
+    _chk(rc, "linear_wgrad_adam_dgrad")
+    return True
+
+
 def linear_wgrad_sgdm(dy, x, w, mw, b, mb, *, lr, momentum=0.9, weight_decay=0.0, fresh: bool = False,
                       sidx=None, prec=None) -> None:
     """Fused ``dw = dy.T @ x`` + SGD-momentum update of (w, b) and their momentum buffers (same layout rules
@@ -280,11 +307,11 @@ def conv1_wgrad(g, code, data, sidx, dw, db, ks: int, prec=None) -> None:
 
 
 def _prep_dtype(prec):
-    return torch.float32 if _prec(prec) == PRECISIONS["fp32"] else torch.bfloat16
+    return torch.float32 if _prec(prec) == PRECISIONS["fp32-mfma"] else torch.bfloat16
 
 
 def _prep_terms(prec) -> int:
-    return SPLIT_TERMS if _prec(prec) == PRECISIONS["fp32-split"] else 1
+    return SPLIT_TERMS if _prec(prec) == PRECISIONS["fp32"] else 1
 
 
 def conv2_prep_alloc(K: int, ks: int, device, prec=None) -> torch.Tensor:

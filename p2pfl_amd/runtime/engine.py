@@ -326,6 +326,13 @@ class HipEngine(ShardEngine):
         self._tail_cache: Dict[tuple, torch.Tensor] = {}
         # big linear layers: weight gradient fused with the optimizer update (gradient never hits HBM)
         self._fused = set()
+        # The fused update of a big layer can also emit that layer's data gradient (one pass over the weights less),
+        # at the price of the convolution backward no longer running BESIDE the update. A gain where nothing overlaps
+        # (default policy "fp32": 310 -> 290 ms per headline round), a loss where something does ("fp32-mfma":
+        # 336 -> 340 ms, its small-footprint convolution blocks take whole CUs from the update; "bf16": the short
+        # convolutions hide completely). P2PFL_FUSE_DGRAD=0/1 overrides for the fp32 policies.
+        env = os.environ.get("P2PFL_FUSE_DGRAD")
+        self._fuse_dgrad = self.precision != "bf16" and (self.precision == "fp32" if env is None else env != "0")
         self._adam_ranges = [(0, L.row_stride)]      # slab ranges the element-wise optimizer kernel owns
         if o.kind in ("adam", "sgd") and fuse_optimizer and not os.environ.get("P2PFL_NO_FUSE"):
             cut = []
@@ -508,13 +515,19 @@ class HipEngine(ShardEngine):
                 else:
                     xin = self.act[i - 1].flatten(2) if self.act[i - 1].dim() > 3 else self.act[i - 1]
                 dy_next = None
+                took = False
                 if i > 0:   # data gradient first: it needs the weights BEFORE the fused update below
                     prev = layers[i - 1]
                     mask = self.act[i - 1] if (prev.kind == "linear" and prev.relu) else None
                     dx = self.dact[i - 1].flatten(2) if self.dact[i - 1].dim() > 3 else self.dact[i - 1]
-                    hip.linear_dgrad(dy, W, mask, dx)
+                    if i in self._fused and mask is None and self._fuse_dgrad:
+                        took = self._fused_update(l, dy, xin, step_index, sidx=gather, dx=dx)
+                    if not took:
+                        hip.linear_dgrad(dy, W, mask, dx)
                     dy_next = self.dact[i - 1]
-                if i in self._fused:
+                if took:
+                    pass
+                elif i in self._fused:
                     self._fused_update(l, dy, xin, step_index, sidx=gather)
                 else:
                     hip.linear_wgrad(dy, xin, gW, gb, sidx=gather)
@@ -527,13 +540,23 @@ class HipEngine(ShardEngine):
             else:  # conv1pool (first layer: no data gradient)
                 hip.conv1_wgrad(dy, self.code[i], data, sidx, gW, gb, l.ksize)
 
-    def _fused_update(self, l, dy, xin, step_index: int, sidx=None) -> None:
-        """Weight gradient of a big linear layer + its optimizer update in one kernel."""
+    def _fused_update(self, l, dy, xin, step_index: int, sidx=None, dx=None) -> bool:
+        """Weight gradient of a big linear layer + its optimizer update in one kernel. With ``dx`` the kernel is
+        also asked for the layer's data gradient (one pass over the weights less, fp32 policies + Adam); False: it
+        declined and NOTHING ran - the caller runs ``linear_dgrad`` and calls again without ``dx``."""
         o = self.spec.optim
         Wb, Mb = self._w(self.params, l), self._w(self.m, l)
         # the reference builds a new optimizer every round: in its first step the moments are zero, so the
         # kernel neither reads them nor do they have to be cleared beforehand (see reset_optimizer)
         fresh = step_index == 1 and not self.persist_optimizer
+        if dx is not None:
+            if o.kind != "adam":
+                return False
+            Vb = self._w(self.v, l)
+            return self.hip.linear_wgrad_adam_dgrad(
+                dy, xin, Wb[0], Mb[0], Vb[0], Wb[1], Mb[1], Vb[1], dx, lr=o.lr, beta1=o.beta1, beta2=o.beta2, eps=o.eps,
+                weight_decay=o.weight_decay, t=step_index,
+                bc=self._bc_buf[step_index - 1] if self._bc_buf is not None else None, fresh=fresh, sidx=sidx)
         if o.kind == "adam":
             Vb = self._w(self.v, l)
             self.hip.linear_wgrad_adam(dy, xin, Wb[0], Mb[0], Vb[0], Wb[1], Mb[1], Vb[1], lr=o.lr, beta1=o.beta1,
@@ -543,6 +566,7 @@ class HipEngine(ShardEngine):
         else:
             self.hip.linear_wgrad_sgdm(dy, xin, Wb[0], Mb[0], Wb[1], Mb[1], lr=o.lr, momentum=o.momentum,
                                        weight_decay=o.weight_decay, fresh=fresh, sidx=sidx)
+        return True
 
     def _optim_step(self, step_index: int) -> None:
         o = self.spec.optim
@@ -659,10 +683,18 @@ class HipEngine(ShardEngine):
             xin = conv_out.flatten(2) if i == nc else self.act[i - 1]
             prev = layers[i - 1]
             mask = self.act[i - 1] if (prev.kind == "linear" and prev.relu) else None
-            hip.linear_dgrad(self.dact[i], W, mask, self.dact[i - 1].flatten(2))
+            took = False
+            if i in self._fused and mask is None and self._fuse_dgrad:
+                # the update kernel hands out the data gradient itself (fp32: the convolutions behind it cannot
+                # hide under the update anyway, see docs/kernels.rst), so the side stream is released after it
+                took = self._fused_update(l, self.dact[i], xin, step_index, dx=self.dact[i - 1].flatten(2))
+            if not took:
+                hip.linear_dgrad(self.dact[i], W, mask, self.dact[i - 1].flatten(2))
             if i == nc:
                 side.wait_stream(main)
-            if i in self._fused:
+            if took:
+                pass
+            elif i in self._fused:
                 self._fused_update(l, self.dact[i], xin, step_index)
             else:
                 gW, gb = self._w(self.grads, l)

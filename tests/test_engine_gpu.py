@@ -20,7 +20,7 @@ def _pair(name, K=3, n=64, n_val=16, n_test=40, fuse=True, precision="fp32"):
     return spec, h, e
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp32-split", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32-mfma", "fp32", "bf16"])
 @pytest.mark.parametrize("name", ["mnist-mlp", "mnist-cnn", "femnist-cnn"])
 def test_first_step_gradients_match_autograd(name, precision):
     spec, h, e = _pair(name, fuse=False, precision=precision)
@@ -53,7 +53,7 @@ def test_first_step_gradients_match_autograd(name, precision):
                 assert err < 0.12 and cos > 0.99, f"{name} {pname}: rel err {err:.3e} cos {cos:.5f}"
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp32-split", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32-mfma", "fp32", "bf16"])
 @pytest.mark.parametrize("name,graph", [("mnist-mlp", True), ("mnist-cnn", True), ("femnist-cnn", False)])
 def test_training_tracks_eager_engine(name, graph, precision):
     spec, h, e = _pair(name, precision=precision)
@@ -238,7 +238,7 @@ def test_two_ranks_on_one_gpu_match_single_rank(kind, encrypt):
     assert torch.allclose(got, want, atol=1e-5, rtol=1e-4), (got - want).abs().max()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp32-split"])
+@pytest.mark.parametrize("precision", ["fp32-mfma", "fp32"])
 def test_hundred_clients_one_round_matches_eager_fp32(precision):
     """100 co-resident MNIST-CNN clients (the headline shard shape: two-stream captured graph, fused update), one
     local-training round, fp32: parameters agree with 100 eager torch.nn + torch.optim.Adam clients to 1e-4."""
@@ -256,7 +256,7 @@ def test_hundred_clients_one_round_matches_eager_fp32(precision):
     assert rel < 2e-2, rel
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp32-split"])
+@pytest.mark.parametrize("precision", ["fp32-mfma", "fp32"])
 def test_hundred_clients_sgd_round_matches_eager_fp32(precision):
     """Same with the FEMNIST CNN, whose SGD-momentum update is linear in the gradient (no normalisation that
     amplifies round-off): after a whole round the fp32 engine and 100 eager torch.optim.SGD clients agree to 1e-6."""

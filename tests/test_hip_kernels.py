@@ -1,8 +1,9 @@
 """Numerics of every gfx950 kernel against a plain PyTorch fp32 reference of the same op.
 
-Every matrix-core kernel exists in two precisions (``prec`` fixture): "fp32" (v_mfma_f32_32x32x2_f32, exact fp32
-fma chains - the default and the reference's precision) must match the fp32 reference to round-off
-(max-normalised error <= 2e-5 dense, <= 2e-4 convolutions: MIOpen's own fp32 algorithms differ by that much);
+Every matrix-core kernel exists per precision policy (``prec`` fixture): "fp32" (the default, the reference's
+precision: v_mfma_f32_32x32x2_f32, with the stage-2 convolutions on an exact 3-term bf16 split) and "fp32-mfma"
+(nothing but fp32 MFMAs) must both match the fp32 reference to round-off (max-normalised error <= 2e-5 dense,
+<= 2e-4 convolutions: MIOpen's own fp32 algorithms differ by that much);
 "bf16" rounds the operands to bf16 (fp32 accumulate) and is compared with a bf16-appropriate tolerance.
 VALU kernels (CE, optimizers, FedAvg, AES) must match to fp32 round-off / exactly.
 """
@@ -21,7 +22,7 @@ def hip():
     return h
 
 
-@pytest.fixture(params=["fp32", "fp32-split", "bf16"])
+@pytest.fixture(params=["fp32-mfma", "fp32", "bf16"])
 def prec(request):
     """Runs the test once per precision policy, as the default of every product wrapper."""
     from p2pfl_amd.ops import hip as h
@@ -31,8 +32,8 @@ def prec(request):
     h.set_default_precision(old)
 
 
-TOL_DENSE = {"fp32": 2e-5, "fp32-split": 2e-5, "bf16": 2e-2}
-TOL_CONV = {"fp32": 2e-4, "fp32-split": 2e-4, "bf16": 2e-2}
+TOL_DENSE = {"fp32-mfma": 2e-5, "fp32": 2e-5, "bf16": 2e-2}
+TOL_CONV = {"fp32-mfma": 2e-4, "fp32": 2e-4, "bf16": 2e-2}
 
 
 def rel_err(a, b):
@@ -265,8 +266,8 @@ def test_conv1_wgrad(ks, B, Fm, K, prec):
 @pytest.mark.parametrize("ks,B,K", [(5, 32, 2), (3, 32, 2), (5, 9, 3), (5, 32, 11), (3, 7, 9)])
 def test_conv2_fwd(ks, B, K, prec, cores):
     h = hip()
-    if cores and prec != "fp32":
-        pytest.skip("co-resident (small-footprint) variants exist for fp32 only")
+    if cores and prec != "fp32-mfma":
+        pytest.skip("co-resident (small-footprint) variants exist for the fp32 MFMA kernels only")
     Cin, Cout = 32, 64
     a1 = torch.randn(K, B, Cin, 196, device=DEV).relu()
     w = slab_view(K, (Cout, Cin * ks * ks)) * 0.05
@@ -287,8 +288,8 @@ def test_conv2_fwd(ks, B, K, prec, cores):
                                     (5, 32, 100)])
 def test_conv2_wgrad_dgrad(ks, B, K, prec, cores):
     h = hip()
-    if cores and prec != "fp32":
-        pytest.skip("co-resident (small-footprint) variants exist for fp32 only")
+    if cores and prec != "fp32-mfma":
+        pytest.skip("co-resident (small-footprint) variants exist for the fp32 MFMA kernels only")
     Cin, Cout = 32, 64
     a1 = torch.randn(K, B, Cin, 196, device=DEV).relu()
     w = slab_view(K, (Cout, Cin * ks * ks)) * 0.05
@@ -365,19 +366,19 @@ def test_conv_shapes_fuzz():
 
     @settings(max_examples=14, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
     @given(K=st.integers(1, 19), B=st.integers(1, 37), ks=st.sampled_from([3, 5]),
-           precision=st.sampled_from(["fp32", "fp32-split", "bf16"]), F1=st.sampled_from([32]))
+           precision=st.sampled_from(["fp32-mfma", "fp32", "bf16"]), F1=st.sampled_from([32]))
     def run(K, B, ks, precision, F1):
         _conv_fuzz_case(K, B, ks, precision, F1)
 
     run()
     for K, B, ks in ((9, 1, 5), (17, 3, 3), (1, 33, 5)):            # corners, always
-        for precision in ("fp32", "fp32-split", "bf16"):
+        for precision in ("fp32-mfma", "fp32", "bf16"):
             _conv_fuzz_case(K, B, ks, precision, 32)
 
 
 @pytest.mark.parametrize("ks", [5, 3])
 def test_conv2_split_is_fp32_accurate(ks):
-    """The three-term bf16 split (fp32-split) against a float64 oracle: its error must be in the class of the fp32
+    """The three-term bf16 split (the stage-2 convolutions of the default "fp32" policy) against a float64 oracle: its error must be in the class of the fp32
     MFMA kernels' own rounding error (both accumulate in fp32), nowhere near bf16's."""
     h = hip()
     K, B, Cin, Cout = 2, 16, 32, 64
@@ -386,7 +387,7 @@ def test_conv2_split_is_fp32_accurate(ks):
     b = slab_view(K, (Cout,)) * 0.1
     g = torch.randn(K, B, Cout, 49, device=DEV)
     err = {}
-    for prec in ("fp32", "fp32-split", "bf16"):
+    for prec in ("fp32-mfma", "fp32", "bf16"):
         a2 = torch.empty(K, B, Cout, 49, device=DEV)
         code = torch.empty(K, B, Cout, 49, dtype=torch.uint8, device=DEV)
         dw = slab_view(K, (Cout, Cin * ks * ks))
@@ -412,9 +413,9 @@ def test_conv2_split_is_fp32_accurate(ks):
         err[prec] = e
     print("conv2 max rel err vs float64 [fwd, wgrad, dgrad, bias]:", err)
     for i in range(4):
-        assert err["fp32-split"][i] < 4 * err["fp32"][i] + 2e-7, (i, err)
-        assert err["fp32-split"][i] < 5e-6, (i, err)
-    assert err["bf16"][0] > 100 * err["fp32-split"][0]
+        assert err["fp32"][i] < 4 * err["fp32-mfma"][i] + 2e-7, (i, err)
+        assert err["fp32"][i] < 5e-6, (i, err)
+    assert err["bf16"][0] > 100 * err["fp32"][0]
 
 
 @pytest.mark.parametrize("C,B,nv", [(10, 32, 32), (62, 32, 28), (10, 100, 77), (62, 256, 200), (17, 40, 40), (64, 5, 3)])
@@ -570,7 +571,7 @@ def test_linear_wgrad_adam_against_torch_optim(K, B, In, Out, wd):
     for t in range(1, 4):
         dy = torch.randn(K, B, Out, device=DEV) * 0.1
         x = torch.randn(K, B, In, device=DEV)
-        h.linear_wgrad_adam(dy, x, w, mw, vw, b, mb, vb, lr=1e-3, weight_decay=wd, t=t, fresh=(t == 1), prec="fp32")
+        h.linear_wgrad_adam(dy, x, w, mw, vw, b, mb, vb, lr=1e-3, weight_decay=wd, t=t, fresh=(t == 1), prec="fp32-mfma")
         for k in range(K):
             ref_w[k].grad = dy[k].T @ x[k]
             ref_b[k].grad = dy[k].sum(0)
@@ -583,6 +584,44 @@ def test_linear_wgrad_adam_against_torch_optim(K, B, In, Out, wd):
             diff = (got - want).abs()
             assert (diff > 2e-6 + 1e-5 * want.abs()).float().mean().item() < 1e-5
             assert diff.max().item() <= 3 * 2e-3
+
+
+@pytest.mark.parametrize("precision", ["fp32-mfma", "fp32"])
+@pytest.mark.parametrize("K,B,In,Out,wd", [(3, 32, 3136, 2048, 0.0), (2, 20, 132, 70, 1e-2), (1, 32, 784, 300, 0.0),
+                                            (11, 7, 3136, 256, 0.0)])
+def test_linear_wgrad_adam_dgrad_fused(K, B, In, Out, wd, precision):
+    """The fused update that also emits the data gradient: weights / moments BITWISE equal to the plain fused update
+    (same products, same order), dx = dy @ w_before against torch at fp32 tolerance; three steps (fresh first)."""
+    h = hip()
+    torch.manual_seed(7)
+    n = In * Out
+    P = n + 64 - n % 64 + 4096
+    base = [torch.randn(K, P, device=DEV) * 0.05, torch.zeros(K, P, device=DEV), torch.zeros(K, P, device=DEV)]
+    slabs_a = [t.clone() for t in base]
+    slabs_b = [t.clone() for t in base]
+    view = lambda s: (s[:, :n].unflatten(1, (Out, In)), s[:, P - 4096:P - 4096 + Out])
+    A = [view(t) for t in slabs_a]
+    Bv = [view(t) for t in slabs_b]
+    n_ids = 40
+    for t in range(1, 4):
+        dy = torch.randn(K, B, Out, device=DEV) * 0.1
+        x = torch.randn(K, B, In, device=DEV)
+        dx = torch.full((K, B, In), float("nan"), device=DEV)
+        w_before = A[0][0].clone()
+        took = h.linear_wgrad_adam_dgrad(dy, x, A[0][0], A[1][0], A[2][0], A[0][1], A[1][1], A[2][1], dx, lr=1e-3,
+                                         weight_decay=wd, t=t, fresh=(t == 1), prec=precision)
+        assert took
+        h.linear_wgrad_adam(dy, x, Bv[0][0], Bv[1][0], Bv[2][0], Bv[0][1], Bv[1][1], Bv[2][1], lr=1e-3, weight_decay=wd,
+                            t=t, fresh=(t == 1), prec=precision)
+        for sa, sb in zip(slabs_a, slabs_b):
+            assert torch.equal(sa, sb)
+        ref = torch.einsum("kbo,koi->kbi", dy, w_before)
+        assert torch.isfinite(dx).all()
+        assert rel_err(dx, ref) < TOL_DENSE[precision]
+    # bf16 and unsupported shapes decline (the caller then runs the two kernels)
+    dx = torch.empty(K, B, In, device=DEV)
+    assert not h.linear_wgrad_adam_dgrad(dy, x, A[0][0], A[1][0], A[2][0], A[0][1], A[1][1], A[2][1], dx, lr=1e-3, t=4,
+                                         prec="bf16")
 
 
 @pytest.mark.parametrize("K,B,In,Out,wd", [(2, 32, 3136, 62, 0.0), (3, 20, 130, 70, 1e-3)])
@@ -601,7 +640,7 @@ def test_linear_wgrad_sgdm_against_torch_optim(K, B, In, Out, wd):
     for t in range(1, 4):
         dy = torch.randn(K, B, Out, device=DEV) * 0.1
         x = torch.randn(K, B, In, device=DEV)
-        h.linear_wgrad_sgdm(dy, x, w, mw, b, mb, lr=1e-2, momentum=0.9, weight_decay=wd, fresh=(t == 1), prec="fp32")
+        h.linear_wgrad_sgdm(dy, x, w, mw, b, mb, lr=1e-2, momentum=0.9, weight_decay=wd, fresh=(t == 1), prec="fp32-mfma")
         for k in range(K):
             ref_w[k].grad = dy[k].T @ x[k]
             ref_b[k].grad = dy[k].sum(0)

@@ -4,7 +4,7 @@ import torch
 sys.path.insert(0, ".")
 from tests.test_engine_gpu import _pair
 
-spec, h, e = _pair("mnist-cnn", precision="fp32")
+spec, h, e = _pair("mnist-cnn", precision="fp32-mfma")
 p0 = h.params.clone()
 # one un-fused step: gradients
 K, B = h.K, h.B

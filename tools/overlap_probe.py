@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, ".")
 from p2pfl_amd.ops import hip
 
-prec = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+prec = sys.argv[1] if len(sys.argv) > 1 else "fp32-mfma"
 K, B = 100, 32
 dev = "cuda"
 h = hip.bound(prec)
@@ -29,7 +29,7 @@ dw2, db2 = torch.empty(K, 64, 800, device=dev), torch.empty(K, 64, device=dev)
 wprep = h.conv2_prep_alloc(K, 5, dev)
 h.conv2_prep(w2, wprep, 5)
 scratch = h.conv2_wgrad_scratch(K, B, 5, dev)
-co = dict(coresident=True) if prec == "fp32" else {}
+co = dict(coresident=True) if prec == "fp32-mfma" else {}
 
 def update():
     h.linear_wgrad_adam(dy, x, w, mw, vw, b, mb, vb, lr=1e-3, t=2)
@@ -81,7 +81,7 @@ for name, f in convs.items():
 # ---- synthetic co-runners (tools/probe/burn.hip): what exactly does the update kernel lose time to?
 import ctypes, os
 lib_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe", "libburn.so")
-if os.path.exists(lib_path) and prec == "fp32":
+if os.path.exists(lib_path) and prec == "fp32-mfma":
     burn = ctypes.CDLL(lib_path)
     burn.burn_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     out = torch.zeros(4, device=dev)

@@ -1,7 +1,7 @@
 import sys, torch
 sys.path.insert(0, ".")
 from p2pfl_amd.ops import hip
-h = hip.bound("fp32-split")
+h = hip.bound("fp32")
 K, B, dev = 100, 32, "cuda"
 a1 = torch.randn(K, B, 32, 196, device=dev).relu()
 code = torch.randint(0, 5, (K, B, 64, 49), device=dev).to(torch.uint8)

@@ -189,7 +189,7 @@ def main() -> None:
     ref_run = None
     n_local = fed.n_local
     events = [[round(t, 1), what, node] for t, what, node in fed.membership.events][:64]
-    if (args.impl == "hip" and args.dtype == "fp32" and not args.no_reference_run and not args.cpu
+    if (args.impl == "hip" and args.dtype == "fp32" and not args.no_reference_run and not args.cpu and world == 1
             and spec.name in ("mnist-cnn", "femnist-cnn")):
         n_ref = max(1, min(args.steps, 5))
         del fed

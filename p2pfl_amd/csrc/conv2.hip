@@ -1043,15 +1043,15 @@ static void wgrad_split(int K, int B, int KS, int cus, int& np, int& ns) {
 }
 
 // Batch splits of the split-operand weight gradient (one block per CU at a time, 2 * K * ns blocks): the count
-// <= 16 with the best (CU fill of the last round) x (evenness of the sample split). More splits must buy > 15 %:
+// <= 8 with the best (CU fill of the last round) x (evenness of the sample split). More splits must buy > 15 %:
 // partials cost a second kernel (measured, 100 clients x 32 samples: 1 split 0.426 ms, 5 splits 0.441 ms although
-// the blocks alone are 14 % better packed). 100 clients -> 1; 1000 -> 1; 10 -> 11.
+// the blocks alone are 14 % better packed; 16 splits 0.548 ms). 100 clients -> 1; 1000 -> 1; 10 -> 8.
 static int wgrad_split_batches(int K, int B, int cus) {
     static const int forced = [] { const char* e = getenv("P2PFL_WGRAD_NS"); return e ? atoi(e) : 0; }();
     if (forced > 0) return forced > B ? B : forced;
     int best = 1;
     double best_eff = 0.0;
-    for (int ns = 1; ns <= 16 && ns <= B; ++ns) {
+    for (int ns = 1; ns <= 8 && ns <= B; ++ns) {
         const long blocks = 2L * K * ns;
         const double fill = (double)blocks / (double)(cdiv((int)blocks, cus) * (long)cus);
         const double even = ((double)B / ns) / (double)cdiv(B, ns);

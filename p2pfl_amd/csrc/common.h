@@ -14,9 +14,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 constexpr int WAVE = 64;
 
 // Precision policy of the matrix products (argument `prec` of the launchers):
-//   PREC_F32  - fp32 operands on v_mfma_f32_32x32x2_f32: exact fp32 fma chains, the reference's precision
+//   PREC_F32  - ("fp32-mfma") fp32 operands on v_mfma_f32_32x32x2_f32 everywhere: exact fp32 fma chains
 //   PREC_BF16 - operands rounded to bf16, fp32 accumulation (16x the matrix-core rate)
-//   PREC_F32_SPLIT - as PREC_F32, except that the stage-2 convolutions (the MFMA-bound kernels of the step) form their
+//   PREC_F32_SPLIT - ("fp32", the default policy and the reference's precision) as PREC_F32, except that the stage-2 convolutions (the MFMA-bound kernels of the step) form their
 //               fp32 products from three bf16 terms per operand, a = a0 + a1 + a2 EXACTLY (3 x 8 significand bits),
 //               keeping the six products a_i * b_j with i + j <= 2 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
 //               every kept product is exact, the dropped ones are <= 2^-24 |a b| (below half an fp32 ulp of the

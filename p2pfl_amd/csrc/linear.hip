@@ -6,6 +6,7 @@
 // (reference: fedstellar/learning/pytorch/mnist/models/mlp.py:156-160,
 //  mnist/models/cnn.py:143-144,157-158, femnist/models/cnn.py:140,151).
 #include "gemm_core.h"
+#include <type_traits>
 
 namespace {
 
@@ -202,16 +203,20 @@ struct LoadXTOnes {
     static constexpr bool ROW_CONTIG = true;
     const float* x; int In, B;
     const int* idx = nullptr;      // optional gather of the batch rows
+    // branch-free: out-of-range elements read a clamped (valid) address and are replaced afterwards, so the eight
+    // (gathered: two-level) loads of a chunk are all in flight together instead of one guarded load after the other
     __device__ __forceinline__ void load8(int row, int k, float (&v)[8]) const {
+        const int rowc = min(row, In - 1);
+        int src[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float t = 0.f;
-            if (k + j < B) {
-                if (row < In) t = x[(size_t)(idx ? idx[k + j] : k + j) * In + row];
-                else if (row == In) t = 1.f;
-            }
-            v[j] = t;
+            const int kc = min(k + j, B - 1);
+            src[j] = idx ? idx[kc] : kc;
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = x[(size_t)src[j] * In + rowc];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (k + j < B) ? (row < In ? v[j] : (row == In ? 1.f : 0.f)) : 0.f;
     }
 };
 
@@ -398,33 +403,28 @@ void linear_wgrad_adam_kernel(WgradAdamArgs a) {
 // Cost: 64 more MFMAs per wave and row tile (as many as the weight gradient itself) in a kernel whose matrix cores
 // idle 91 % of the time; saved: the separate data-gradient kernel's pass over the weights (2.6 GB for 100 clients).
 // ---------------------------------------------------------------------------------------
-template <bool FRESH>
-__global__ __launch_bounds__(256, 2)
-void linear_wgrad_adam_dgrad_kernel(WgradAdamArgs a, float* dx_all, long dx_cs) {
-    constexpr int BK = GEMM_BK, LDK = BK + lds_pad<float>();
-    __shared__ __attribute__((aligned(16))) float sa[2][128 * LDK];
-    __shared__ __attribute__((aligned(16))) float sb[128 * LDK];
-    const int c = blockIdx.y, n0 = blockIdx.x * 128;
+// The epilogue is a software pipeline: the p / m / v loads of a row do not depend on the gradient, so they are
+// issued D rows (D x 3 float4 per lane) ahead of their use - across row tiles too, i.e. they fly while the next
+// tile's MFMAs run. Before (3 loads, wait, update, 3 stores, per row: 16 full memory latencies per tile with 3 KB
+// per wave in flight) the kernel was bound by bytes in flight per CU, not by HBM: its time grew 1:1 as CUs were
+// masked away (tools/probe/cumask_probe.py: 3.08 ms on 256 CUs, 5.0 on 128).
+// FULL: the strip has 128 valid columns and M % 128 == 0 - no predicates at all. Otherwise out-of-range lanes load
+// from a clamped (valid) address and are masked at the stores; column N is the bias (In % 4 == 0 is required, so a
+// float4 is either wholly inside or wholly outside the weight matrix).
+template <bool FRESH, bool FULL, int D>
+__device__ __forceinline__ void fused_update_strip(const WgradAdamArgs& a, const EpiWgradAdam<FRESH>& epi, float* dx,
+                                                   float (&sa)[2][128 * (GEMM_BK + 4)], float (&sb)[128 * (GEMM_BK + 4)],
+                                                   const LoadColMajorK& al, int n0) {
+    constexpr int BK = GEMM_BK, LDK = BK + 4;
+    static_assert(16 % D == 0, "ring slots must map statically across row tiles");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
-    LoadColMajorK al{a.dy + c * a.dy_cs, a.Out, a.B, a.Out};
-    LoadXTOnes bl{a.x + c * a.x_cs, a.In, a.B, a.sidx ? a.sidx + c * a.s_cs : nullptr};
-    const float ib1 = a.h.bc ? a.h.bc[0] : a.h.inv_bc1;
-    const float isb2 = a.h.bc ? a.h.bc[1] : a.h.inv_sqrt_bc2;
-    const long wo = c * a.w_cs, bo = c * a.b_cs;
-    const EpiWgradAdam<FRESH> epi{a.w + wo, a.mw + wo, a.vw + wo, a.b + bo, a.mb + bo, a.vb + bo, a.Out, a.In,
-                                  a.h.lr * ib1, a.h.beta1, a.h.beta2, a.h.eps, a.h.weight_decay, isb2};
     const int M = a.Out, N = a.In;
+    const int MT = (M + 127) / 128;
+    const int n = n0 + 4 * r;
+    const bool col_ok = FULL || n < N;
 
     TileStager<128, 256, LoadColMajorK, false, BK, float> sta;
-    {
-        TileStager<128, 256, LoadXTOnes, true, BK, float> stb;
-        stb.load(bl, n0, 0);
-        stb.store(sb);
-    }
-    sta.load(al, 0, 0);
-    sta.store(sa[0]);
-    __syncthreads();
 
     f32x16 accx[4];
 #pragma unroll
@@ -432,11 +432,25 @@ void linear_wgrad_adam_dgrad_kernel(WgradAdamArgs a, float* dx_all, long dx_cs) 
 #pragma unroll
         for (int e = 0; e < 16; ++e) accx[j][e] = 0.f;
 
-    const int MT = (M + 127) / 128;
-    const int n = n0 + 4 * r;
+    // ring of D rows in flight
+    f32x4 rp[D], rm[D], rv[D];
+    auto issue = [&](int mt, int e, int slot) {
+        const int m = mt * 128 + wave * 32 + mfma_row(e, lane);
+        const size_t o = (FULL || (col_ok && m < M)) ? (size_t)m * N + n : 0;
+        rp[slot] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(epi.w + o));
+        if constexpr (!FRESH) {
+            rm[slot] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(epi.mw + o));
+            rv[slot] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(epi.vw + o));
+        }
+    };
+#pragma unroll
+    for (int e = 0; e < D; ++e) issue(0, e, e);
+
     int cur = 0;
-#pragma unroll 1
-    for (int mt = 0; mt < MT; ++mt) {
+    // one 128-row tile; LAST (compile time: the last tile is peeled, so the wait counts of the others never have to
+    // cover a path without prefetches) = nothing follows: no dY staging, no loads for the next tile
+    auto tile = [&](int mt, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
         const int m0 = mt * 128;
         f32x16 acc[4];
 #pragma unroll
@@ -457,54 +471,57 @@ void linear_wgrad_adam_dgrad_kernel(WgradAdamArgs a, float* dx_all, long dx_cs) 
                 for (int j = 0; j < 4; ++j)
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bfr[j][e], acc[j], 0, 0, 0);
         }
-        if (mt + 1 < MT) sta.load(al, m0 + 128, 0);
+        if constexpr (!LAST) sta.load(al, m0 + 128, 0);
 
         // epilogue: Adam on the 32 x 128 piece of this wave, the weights feeding the data gradient on the way
         const float* dyt = sa[cur] + (wave * 32) * LDK + r;          // dY[b = r][row] = dyt[row * LDK]
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
+            const int slot = e % D;
             const int mloc = mfma_row(e, lane);
             const int m = m0 + wave * 32 + mloc;
-            const bool vec = m < M && n + 3 < N;
+            const bool ok = FULL || (col_ok && m < M);
             const size_t o = (size_t)m * N + n;
-            f32x4 pv = {0.f, 0.f, 0.f, 0.f}, mv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (vec) {
-                pv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(epi.w + o));
-                if constexpr (!FRESH) {
-                    mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(epi.mw + o));
-                    vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(epi.vw + o));
-                }
-            } else if (m < M) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (n + j < N) pv[j] = epi.w[o + j];
+            f32x4 pv = rp[slot];
+            f32x4 mv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (!FRESH) { mv = rm[slot]; vv = rv[slot]; }
+            if (e + D < 16) issue(mt, e + D, slot);
+            else if constexpr (!LAST) issue(mt + 1, e + D - 16, slot);
+            if constexpr (!FULL) {
+                if (!ok) pv = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             const float ae = dyt[mloc * LDK];
 #pragma unroll
             for (int j = 0; j < 4; ++j) accx[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, pv[j], accx[j], 0, 0, 0);
-            if (vec) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float gr = acc[j][e] + epi.wd * pv[j];
-                    mv[j] = epi.beta1 * mv[j] + (1.f - epi.beta1) * gr;
-                    vv[j] = epi.beta2 * vv[j] + (1.f - epi.beta2) * gr * gr;
-                    pv[j] -= epi.step * (mv[j] / (sqrtf(vv[j]) * epi.isb2 + epi.eps));
-                }
+            for (int j = 0; j < 4; ++j) {
+                const float gr = acc[j][e] + epi.wd * pv[j];
+                mv[j] = epi.beta1 * mv[j] + (1.f - epi.beta1) * gr;
+                vv[j] = epi.beta2 * vv[j] + (1.f - epi.beta2) * gr * gr;
+                pv[j] -= epi.step * (mv[j] / (sqrtf(vv[j]) * epi.isb2 + epi.eps));
+            }
+            if (ok) {
                 __builtin_nontemporal_store(pv, reinterpret_cast<f32x4*>(epi.w + o));
                 __builtin_nontemporal_store(mv, reinterpret_cast<f32x4*>(epi.mw + o));
                 __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(epi.vw + o));
-            } else if (m < M && n <= N) {
+            }
+        }
+        if constexpr (!FULL) {
+            if (n == N) {                     // the ones row of X^T: bias gradient
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (n + j < N) epi.upd(epi.w + o + j, epi.mw + o + j, epi.vw + o + j, acc[j][e]);
-                    else if (n + j == N) epi.upd(epi.b + m, epi.mb + m, epi.vb + m, acc[j][e]);
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wave * 32 + mfma_row(e, lane);
+                    if (m < M) epi.upd(epi.b + m, epi.mb + m, epi.vb + m, acc[0][e]);
                 }
             }
         }
-        if (mt + 1 < MT) sta.store(sa[cur ^ 1]);
+        if constexpr (!LAST) sta.store(sa[cur ^ 1]);
         __syncthreads();
         cur ^= 1;
-    }
+    };
+#pragma unroll 1
+    for (int mt = 0; mt + 1 < MT; ++mt) tile(mt, std::false_type{});
+    tile(MT - 1, std::true_type{});
 
     // dX strip = sum of the four waves' partials, in wave order
     float* red = sa[0];                     // [32 b][128 n]; the loop's last barrier freed both dY buffers
@@ -521,12 +538,40 @@ void linear_wgrad_adam_dgrad_kernel(WgradAdamArgs a, float* dx_all, long dx_cs) 
         }
         __syncthreads();
     }
-    float* dx = dx_all + c * dx_cs;
     for (int i = threadIdx.x; i < 32 * 32; i += 256) {
         const int b = i >> 5, q = i & 31;
         if (b < a.B && n0 + 4 * q + 3 < N)
             *reinterpret_cast<f32x4*>(dx + (size_t)b * N + n0 + 4 * q) = *reinterpret_cast<const f32x4*>(red + b * 128 + 4 * q);
     }
+}
+
+template <bool FRESH, int D>
+__global__ __launch_bounds__(256, D >= 8 ? 1 : 2)
+void linear_wgrad_adam_dgrad_kernel(WgradAdamArgs a, float* dx_all, long dx_cs) {
+    constexpr int BK = GEMM_BK, LDK = BK + lds_pad<float>();
+    static_assert(LDK == GEMM_BK + 4, "fp32 LDS rows carry 4 floats of padding");
+    __shared__ __attribute__((aligned(16))) float sa[2][128 * LDK];
+    __shared__ __attribute__((aligned(16))) float sb[128 * LDK];
+    const int c = blockIdx.y, n0 = blockIdx.x * 128;
+    LoadColMajorK al{a.dy + c * a.dy_cs, a.Out, a.B, a.Out};
+    LoadXTOnes bl{a.x + c * a.x_cs, a.In, a.B, a.sidx ? a.sidx + c * a.s_cs : nullptr};
+    const float ib1 = a.h.bc ? a.h.bc[0] : a.h.inv_bc1;
+    const float isb2 = a.h.bc ? a.h.bc[1] : a.h.inv_sqrt_bc2;
+    const long wo = c * a.w_cs, bo = c * a.b_cs;
+    const EpiWgradAdam<FRESH> epi{a.w + wo, a.mw + wo, a.vw + wo, a.b + bo, a.mb + bo, a.vb + bo, a.Out, a.In,
+                                  a.h.lr * ib1, a.h.beta1, a.h.beta2, a.h.eps, a.h.weight_decay, isb2};
+    {
+        TileStager<128, 256, LoadXTOnes, true, BK, float> stb;
+        stb.load(bl, n0, 0);
+        stb.store(sb);
+        TileStager<128, 256, LoadColMajorK, false, BK, float> sta;
+        sta.load(al, 0, 0);
+        sta.store(sa[0]);
+    }
+    __syncthreads();
+    float* dx = dx_all + c * dx_cs;
+    if (n0 + 128 <= a.In && (a.Out & 127) == 0) fused_update_strip<FRESH, true, D>(a, epi, dx, sa, sb, al, n0);
+    else fused_update_strip<FRESH, false, D>(a, epi, dx, sa, sb, al, n0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -668,8 +713,20 @@ P2PFL_API int p2pfl_linear_wgrad_adam_dgrad(const float* dy, long dy_cs, const f
                     AdamHyper{lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
                               (float)(1.0 / sqrt(bc2)), bc, fresh}, sidx, s_cs, 0};
     const dim3 grid(cdiv(In + 1, 128), K);
-    if (fresh) hipLaunchKernelGGL(linear_wgrad_adam_dgrad_kernel<true>, grid, dim3(256), 0, stream, a, dx, dx_cs);
-    else hipLaunchKernelGGL(linear_wgrad_adam_dgrad_kernel<false>, grid, dim3(256), 0, stream, a, dx, dx_cs);
+    // rows in flight per lane (ring depth of the epilogue pipeline). 8 rows = 24 float4 per lane need the whole register
+    // file (467 registers: ONE workgroup per CU) and win: 100 clients x 3136x2048 on MI355X 3.26 ms (no pipeline)
+    // -> 3.08 (depth 2, two workgroups per CU, spills) -> 3.01 ms = 5.2 TB/s, which is what ANY in-place
+    // 3-read / 3-write fp32 stream reaches on this part whatever its geometry (tools/probe/stream_geom.hip).
+    // P2PFL_UPDATE_DEPTH=2 selects the shallow variant (experiments).
+    static const int depth = [] { const char* e = getenv("P2PFL_UPDATE_DEPTH"); return e ? atoi(e) : 8; }();
+#define P2PFL_LAUNCH_FUSED(D_)                                                                                          \
+    do {                                                                                                                \
+        if (fresh) hipLaunchKernelGGL((linear_wgrad_adam_dgrad_kernel<true, D_>), grid, dim3(256), 0, stream, a, dx, dx_cs); \
+        else hipLaunchKernelGGL((linear_wgrad_adam_dgrad_kernel<false, D_>), grid, dim3(256), 0, stream, a, dx, dx_cs);   \
+    } while (0)
+    if (depth == 2) P2PFL_LAUNCH_FUSED(2);
+    else P2PFL_LAUNCH_FUSED(8);
+#undef P2PFL_LAUNCH_FUSED
     P2PFL_RETURN_LAST_ERROR();
 }
 

@@ -60,3 +60,19 @@ extern "C" int burn_launch(int which, int blocks, int iters, float* out, hipStre
     else hipLaunchKernelGGL(burn_sleep, dim3(blocks), dim3(256), 0, s, out, iters, 1.0f);
     return (int)hipGetLastError();
 }
+// where does a block run? out[2*b] = XCC id, out[2*b+1] = HW_ID (cu_id bits 11:8, sh 12, se 15:13)
+extern "C" __global__ void whereami(unsigned* out, int spin) {
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    for (int i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(64);
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = xcc; out[2 * blockIdx.x + 1] = hw; }
+}
+extern "C" int whereami_launch(int blocks, int spin, unsigned* out, hipStream_t s) {
+    hipLaunchKernelGGL(whereami, dim3(blocks), dim3(64), 0, s, out, spin);
+    return (int)hipGetLastError();
+}
+// stream restricted to the CUs of a bit mask (hipExtStreamCreateWithCUMask)
+extern "C" int masked_stream_create(hipStream_t* s, int words, const unsigned* mask) {
+    return (int)hipExtStreamCreateWithCUMask(s, (uint32_t)words, mask);
+}

@@ -387,6 +387,12 @@ class HipEngine(ShardEngine):
             # gradient on a third stream, and on the main stream in front of the fused update - no gain over the
             # side stream: 10 clients 313 vs 302 ms, 50 FEMNIST clients 54.6 vs 55.3.)
             self._act_pp = [self.act[self.nc - 1], torch.zeros_like(self.act[self.nc - 1])]
+        # exact-split policy, update without fused data gradient (small shards): the stage-2 weight gradient runs on the
+        # launch stream in front of the fused update (P2PFL_WGRAD_MAIN=0/1 overrides)
+        env = os.environ.get("P2PFL_WGRAD_MAIN")
+        self._wgrad_on_main = (self.overlap and self.nc >= 2 and self.spec.layers[self.nc - 1].kind == "conv2pool"
+                               and (self.precision == "fp32" if env is None else env != "0"))
+        self._wgrad_ev = None
 
     def close(self) -> None:
         """Release the captured graphs now (while the HIP runtime is certainly alive) instead of at
@@ -649,18 +655,34 @@ class HipEngine(ShardEngine):
             x = out
 
     def _conv_backward(self, data, sidx, coresident: bool = False) -> None:
+        """Backward pass of the convolution stages. Under the fused update (``coresident``) the kernels that fit on a
+        CU beside its two workgroups go first - stage-2 data gradient, stage-1 weight gradient - and the stage-2
+        weight gradient (512 threads, 104 KB of LDS in the exact-split policy: it waits for whole free CUs) last, so
+        the chain behind it no longer waits the update out (10 clients: see docs/kernels.rst)."""
         hip = self.hip
+        deferred = []
+        late_wgrad = coresident and not os.environ.get("P2PFL_WGRAD_FIRST")
         for i in range(self.nc - 1, -1, -1):
             l = self.spec.layers[i]
             W, _ = self._w(self.params, l)
             gW, gb = self._w(self.grads, l)
             if l.kind == "conv2pool":
-                hip.conv2_wgrad(self.dact[i], self.code[i], self.act[i - 1], gW, gb, l.ksize,
-                                scratch=self.w2_scratch[i], coresident=coresident)
+                def wgrad(i=i, l=l, gW=gW, gb=gb):
+                    hip.conv2_wgrad(self.dact[i], self.code[i], self.act[i - 1], gW, gb, l.ksize,
+                                    scratch=self.w2_scratch[i], coresident=coresident)
+                if i == self.nc - 1 and getattr(self, "_wgrad_ev", None) is not None:
+                    ev = self._wgrad_ev                       # ran on the launch stream (see _dense_step)
+                    deferred.append(lambda ev=ev: torch.cuda.current_stream().wait_event(ev))
+                elif late_wgrad:
+                    deferred.append(wgrad)
+                else:
+                    wgrad()
                 hip.conv2_dgrad(self.dact[i], self.code[i], W, self.dact[i - 1], l.ksize, wprep=self.wprep[i],
                                 coresident=coresident)
             else:
                 hip.conv1_wgrad(self.dact[i], self.code[i], data, sidx, gW, gb, l.ksize)
+        for fn in deferred:
+            fn()
 
     def _dense_step(self, conv_out, labels, sidx, n_valid, step_index: int, side) -> None:
         """Dense layers of one training step on the current stream: forward, loss, backward. ``side`` is
@@ -692,6 +714,17 @@ class HipEngine(ShardEngine):
                 hip.linear_dgrad(self.dact[i], W, mask, self.dact[i - 1].flatten(2))
             if i == nc:
                 side.wait_stream(main)
+                self._wgrad_ev = None
+                if not took and self._wgrad_on_main:
+                    # exact-split stage-2 weight gradient: a 512-thread / 104 KB block needs a CU to itself and would
+                    # wait the whole update out on the side stream (and the rest of the chain behind it)
+                    j = nc - 1
+                    lj = layers[j]
+                    gWj, gbj = self._w(self.grads, lj)
+                    hip.conv2_wgrad(self.dact[j], self.code[j], self.act[j - 1], gWj, gbj, lj.ksize,
+                                    scratch=self.w2_scratch[j])
+                    self._wgrad_ev = torch.cuda.Event()
+                    self._wgrad_ev.record(main)
             if took:
                 pass
             elif i in self._fused:

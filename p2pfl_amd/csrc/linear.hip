@@ -725,6 +725,7 @@ P2PFL_API int p2pfl_linear_wgrad_adam_dgrad(const float* dy, long dy_cs, const f
         else hipLaunchKernelGGL((linear_wgrad_adam_dgrad_kernel<false, D_>), grid, dim3(256), 0, stream, a, dx, dx_cs);   \
     } while (0)
     if (depth == 2) P2PFL_LAUNCH_FUSED(2);
+    else if (depth == 16) P2PFL_LAUNCH_FUSED(16);
     else P2PFL_LAUNCH_FUSED(8);
 #undef P2PFL_LAUNCH_FUSED
     P2PFL_RETURN_LAST_ERROR();

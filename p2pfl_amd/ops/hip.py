@@ -133,6 +133,8 @@ class _Sig:
     p2pfl_adam_step = [P, P, P, P, L, L, I, F, F, F, F, F, I, P, P]
     p2pfl_sgdm_step = [P, P, P, L, L, I, F, F, F, P]
     p2pfl_fedavg = [P, L, I, P, L, P, L, P, P, P, P, P, I, L, P]
+    p2pfl_fedavg_inplace = [P, L, I, P, L, I, P, P, P, P, P, I, L, P]
+    p2pfl_fedavg_inplace_chunk = [I]
     p2pfl_aes128_ecb = [P, P, P, L, I, P]
 
 
@@ -449,6 +451,24 @@ def fedavg(local, remote, out, src_ptr, src_row, src_w, dst_ptr, dst_row) -> Non
                              _t(src_row, torch.int32).data_ptr(), _t(src_w).data_ptr(),
                              _t(dst_ptr, torch.int32).data_ptr(), _t(dst_row, torch.int32).data_ptr(), G, n,
                              _stream()), "fedavg")
+
+
+def fedavg_inplace(slab, remote, src_ptr, src_row, src_w, dst_ptr, dst_row) -> bool:
+    """:func:`fedavg` with ``out`` = ``slab`` itself: every source row (slab rows, then ``remote`` rows) is read once,
+    whatever the number of groups using it, and the destinations are overwritten in place (csrc/fedavg.hip).
+    False (nothing ran): too many rows for the kernel's LDS pool - reduce into a second slab with :func:`fedavg`."""
+    n_local, n = slab.shape
+    n_remote = int(remote.shape[0]) if remote is not None and remote.numel() else 0
+    lib = load()
+    if int(lib.p2pfl_fedavg_inplace_chunk(n_local + n_remote)) == 0:
+        return False
+    rp, rs = (remote.data_ptr(), remote.stride(0)) if n_remote else (None, 0)
+    G = src_ptr.numel() - 1
+    _chk(lib.p2pfl_fedavg_inplace(_t(slab).data_ptr(), slab.stride(0), n_local, rp, rs, n_remote,
+                                  _t(src_ptr, torch.int32).data_ptr(), _t(src_row, torch.int32).data_ptr(),
+                                  _t(src_w).data_ptr(), _t(dst_ptr, torch.int32).data_ptr(),
+                                  _t(dst_row, torch.int32).data_ptr(), G, n, _stream()), "fedavg_inplace")
+    return True
 
 
 def aes128_ecb(src, dst, round_keys, decrypt: bool) -> None:

@@ -113,3 +113,27 @@ def run_plan(local: torch.Tensor, remote: Optional[torch.Tensor], out: torch.Ten
         hip.fedavg(local, remote, out, p.src_ptr, p.src_row, p.src_w, p.dst_ptr, p.dst_row)
     else:
         fedavg_reference(local, remote, out, plan)
+
+
+def inplace_supported(slab: torch.Tensor, n_remote: int) -> bool:
+    """Can :func:`run_plan_inplace` reduce this slab (+ ``n_remote`` staged rows) in place? (GPU slabs whose rows
+    fit the kernel's LDS pool; ``P2PFL_FEDAVG_TWO_SLABS=1`` forces the two-slab path for A/B runs.)"""
+    import os
+    if not slab.is_cuda or os.environ.get("P2PFL_FEDAVG_TWO_SLABS"):
+        return False
+    from ..ops import hip
+    return int(hip.load().p2pfl_fedavg_inplace_chunk(int(slab.shape[0]) + int(n_remote))) > 0
+
+
+def run_plan_inplace(slab: torch.Tensor, remote: Optional[torch.Tensor], plan: AggregationPlan,
+                     n_remote: int = 0) -> bool:
+    """Execute a plan whose destination slab IS the source slab (``csrc/fedavg.hip``: every source row is read once,
+    destinations are overwritten in place; rows no group writes keep their content). False: not applicable."""
+    if plan.n_groups == 0:
+        return True
+    if not inplace_supported(slab, n_remote):
+        return False
+    from ..ops import hip
+    p = plan if plan.src_ptr.is_cuda else plan.to(slab.device)
+    rem = remote[:n_remote] if (remote is not None and n_remote > 0) else None
+    return hip.fedavg_inplace(slab, rem, p.src_ptr, p.src_row, p.src_w, p.dst_ptr, p.dst_row)

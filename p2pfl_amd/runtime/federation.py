@@ -42,7 +42,7 @@ from ..models.specs import ModelSpec
 from ..parallel.collectives import DeviceExchange
 from ..parallel.planner import link_key, partition_nodes, plan_exchange  # noqa: F401  (re-exported)
 from ..role import Role, default_roles
-from .aggregation import AggregationPlan, build_plan, run_plan
+from .aggregation import AggregationPlan, build_plan, inplace_supported, run_plan, run_plan_inplace
 from .engine import ShardEngine, make_engine
 from .membership import VirtualMembership
 
@@ -263,6 +263,14 @@ class BatchedFederation:
         cached, all_covered = self._plan()
         if cached is None:
             return 0
+        if cached[0] == "rows" and inplace_supported(eng.params, cached[4]):
+            # one slab: the reduce reads every row once and overwrites the destinations in place (no second slab,
+            # no copy back into the slab the captured graphs point at; uncovered rows keep their model by themselves)
+            _, send_lists, recv_lists, plan, n_recv = cached
+            got = self._exchange_rows(send_lists, recv_lists, n_recv)
+            if run_plan_inplace(eng.params, self.staging, plan, n_recv):
+                return got
+            raise RuntimeError("in-place FedAvg declined a plan it had accepted")
         out = eng.alt_slab()
         if not all_covered:
             out.copy_(eng.params)        # rows nobody writes (dead / isolated nodes) keep their model
@@ -324,8 +332,10 @@ class BatchedFederation:
         costs what every round costs; leaves models, optimizer state and counters untouched."""
         if hasattr(self.engine, "prepare"):
             self.engine.prepare(self.epochs)
-        self._plan()
-        self.engine.alt_slab()
+        cached, _ = self._plan()
+        if self.virtual_devices > 1 or cached is None or not (cached[0] == "rows" and
+                                                             inplace_supported(self.engine.params, cached[4])):
+            self.engine.alt_slab()       # (the in-place reduce needs no second slab)
 
     def _plan(self):
         """(exchange plan, all local rows covered) for the current membership / links / roles.

@@ -507,6 +507,41 @@ def test_fedavg_groups(n_local, n_remote, P):
     assert torch.allclose(out, ref, atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("n_local,n_remote,P", [(5, 0, 1024), (12, 7, 4100), (100, 0, 50_000), (100, 100, 8192), (300, 40, 2052), (600, 0, 1024)])
+def test_fedavg_inplace_matches_two_slab_reduce(n_local, n_remote, P):
+    """In-place reduce (every source row read once into LDS, destinations overwritten) == the reference into a second
+    slab; rows no group writes keep their content; more rows than the LDS pool holds -> declined, nothing touched."""
+    from p2pfl_amd.runtime.aggregation import build_plan, fedavg_reference, inplace_supported, run_plan_inplace
+    P = (P + 63) // 64 * 64
+    gen = torch.Generator().manual_seed(1)
+    local = torch.randn(n_local, P, generator=gen).to(DEV)
+    remote = torch.randn(max(n_remote, 1) + 3, P, generator=gen).to(DEV)    # staging may be larger than what is used
+    pool_n = n_local + n_remote
+    groups = []
+    dsts = torch.randperm(n_local, generator=gen).tolist()
+    n_written = max(1, n_local - 2)                                         # the last two rows stay unwritten
+    i = 0
+    while i < n_written:
+        k = int(torch.randint(1, min(pool_n, 7) + 1, (1,), generator=gen))
+        nd = int(torch.randint(1, 4, (1,), generator=gen))
+        srcs = torch.randperm(pool_n, generator=gen)[:k].tolist()
+        groups.append((srcs, torch.randint(1, 600, (k,), generator=gen).tolist(), dsts[i:min(i + nd, n_written)]))
+        i += nd
+    plan = build_plan(groups)
+    ref = local.clone()
+    fedavg_reference(local, remote[:n_remote] if n_remote else None, ref, plan)
+    before = local.clone()
+    ok = run_plan_inplace(local, remote, plan, n_remote)
+    assert ok == inplace_supported(before, n_remote)
+    if pool_n * 32 * 4 > 64 * 1024:
+        assert not ok and torch.equal(local, before)
+        return
+    assert ok
+    assert torch.allclose(local, ref, atol=1e-5, rtol=1e-5)
+    untouched = dsts[n_written:]
+    assert torch.equal(local[untouched], before[untouched])
+
+
 def test_aes128_ecb_known_answer_and_roundtrip():
     h = hip()
     from p2pfl_amd.utils.aes import expand_key, ecb_host

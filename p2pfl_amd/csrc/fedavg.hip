@@ -13,6 +13,8 @@
 // receives rows of other GPUs over RCCL (row id >= n_local).
 //
 // Replaces the Python double loop of fedstellar/learning/aggregators/fedavg.py:40-60.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void fedavg_inplace_kernel(FedAvgArgs a, int n
     const long col4 = (long)blockIdx.x * C4;
     const int lc = threadIdx.x % C4, lr = threadIdx.x / C4;
     const bool col_ok = col4 + lc < a.n4;
-    constexpr int U = 4;
+    constexpr int U = 8;                     // row pieces in flight per thread
     for (int r0 = 0; r0 < n_rows; r0 += RPP * U) {
         float4 v[U];
 #pragma unroll
@@ -113,14 +115,19 @@ __global__ __launch_bounds__(256) void fedavg_inplace_kernel(FedAvgArgs a, int n
 }  // namespace
 
 // LDS bytes the in-place kernel may use per block (two to three blocks per CU)
-static constexpr long FEDAVG_INPLACE_LDS = 64 * 1024;
+// LDS bytes per block the in-place kernel aims at: 32 KB = four to five blocks per CU, whose load and store phases
+// cover each other (100 rows x 6.5 M on MI355X: 16 KB 1.37 ms, 32 KB 1.20 ms, 64 KB 1.57 ms; tools/probe/fedavg_probe.py)
+static long fedavg_inplace_lds() {
+    static const long v = [] { const char* e = getenv("P2PFL_FEDAVG_LDS_KB"); return (e ? atol(e) : 32) * 1024; }();
+    return v;
+}
 
 // Column chunk (floats) of the in-place reduce for n_rows source rows, 0: not applicable (too many rows for 128-byte
-// row pieces in LDS: use p2pfl_fedavg into a second slab)
+// row pieces in 64 KB of LDS: use p2pfl_fedavg into a second slab)
 P2PFL_API int p2pfl_fedavg_inplace_chunk(int n_rows) {
     for (int c = 256; c >= 32; c >>= 1)
-        if ((long)n_rows * c * 4 <= FEDAVG_INPLACE_LDS) return c;
-    return 0;
+        if ((long)n_rows * c * 4 <= fedavg_inplace_lds()) return c;
+    return (long)n_rows * 32 * 4 <= 64 * 1024 ? 32 : 0;
 }
 
 // slab[dst] = sum w * pool[src], pool = slab rows [0, n_local) then `remote` rows [0, n_remote); see the kernel

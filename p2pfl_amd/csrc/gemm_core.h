@@ -31,6 +31,8 @@
 // Epilogue contract:
 //   __device__ void operator()(const f32x16& acc, int m0, int n0) const;
 //       lane l holds column n0 + (l & 31), rows m0 + (reg&3) + 8*(reg>>2) + 4*(l>>5).
+//   N4 epilogues: static constexpr int BATCH (1: store4(v, m, n) per row; > 1: struct Row + load4(Row&, m, n) for
+//       BATCH rows at once, then finish4(Row&, v, m, n) per row).
 #pragma once
 #include "common.h"
 
@@ -201,12 +203,33 @@ __device__ __forceinline__ void gemm_block_tile(GemmSmem<BM, BN, NBUF, BK, T>& s
     }
 
     if constexpr (N4) {
+        if constexpr (EPI::BATCH > 1) {
+            // read-modify-write epilogues (fused optimizers): the loads of EPI::BATCH rows are issued together, then
+            // the rows are finished one by one - BATCH x the bytes in flight of the load-wait-store row loop
+            constexpr int G = EPI::BATCH;
+            static_assert(16 % G == 0, "batch must divide the 16 accumulator rows");
 #pragma unroll
-        for (int i = 0; i < RM; ++i)
+            for (int i = 0; i < RM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                epi.store4(make_float4(acc[i][0][e], acc[i][1][e], acc[i][2][e], acc[i][3][e]),
-                           m0 + wr * TM + i * 32 + mfma_row(e, lane), n0 + wc * TN + 4 * r);
+                for (int e0 = 0; e0 < 16; e0 += G) {
+                    typename EPI::Row rows[G];
+#pragma unroll
+                    for (int u = 0; u < G; ++u)
+                        epi.load4(rows[u], m0 + wr * TM + i * 32 + mfma_row(e0 + u, lane), n0 + wc * TN + 4 * r);
+#pragma unroll
+                    for (int u = 0; u < G; ++u)
+                        epi.finish4(rows[u], make_float4(acc[i][0][e0 + u], acc[i][1][e0 + u], acc[i][2][e0 + u],
+                                                         acc[i][3][e0 + u]),
+                                    m0 + wr * TM + i * 32 + mfma_row(e0 + u, lane), n0 + wc * TN + 4 * r);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    epi.store4(make_float4(acc[i][0][e], acc[i][1][e], acc[i][2][e], acc[i][3][e]),
+                               m0 + wr * TM + i * 32 + mfma_row(e, lane), n0 + wc * TN + 4 * r);
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < RM; ++i)

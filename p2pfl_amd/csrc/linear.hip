@@ -221,6 +221,7 @@ struct LoadXTOnes {
 };
 
 struct EpiWgradStore {
+    static constexpr int BATCH = 1;
     float* dw; float* db; int M, N;  // M = Out, N = In (column N = bias)
     __device__ __forceinline__ void store4(float4 g, int m, int n) const {
         if (m >= M || n > N) return;
@@ -291,29 +292,38 @@ struct EpiWgradAdam {
         *m = mv; *v = vv;
         *p = pv - step * (mv / (sqrtf(vv) * isb2 + eps));
     }
-    __device__ __forceinline__ void store4(float4 g, int m, int n) const {
-        if (m >= M || n > N) return;
-        if (n + 3 < N && (N & 3) == 0) {
-            // weights and moments are touched exactly once per step: non-temporal both ways (measured on
-            // MI355X, 100 clients x 3136x2048: 2.96 ms plain, 3.09 nt loads only, 2.88 nt loads + stores)
+    // Rows are processed in batches (gemm_block_tile, N4 epilogue): the p / m / v loads of BATCH rows fly together.
+    // weights and moments are touched exactly once per step: non-temporal both ways (measured on
+    // MI355X, 100 clients x 3136x2048: 2.96 ms plain, 3.09 nt loads only, 2.88 nt loads + stores)
+    static constexpr int BATCH = 4;
+    struct Row { f32x4 p, m, v; };
+    __device__ __forceinline__ bool vec(int m, int n) const { return m < M && n + 3 < N && (N & 3) == 0; }
+    __device__ __forceinline__ void load4(Row& r, int m, int n) const {
+        r.p = f32x4{0.f, 0.f, 0.f, 0.f}; r.m = r.p; r.v = r.p;
+        if (vec(m, n)) {
             const size_t o = (size_t)m * N + n;
-            f32x4 pv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + o));
-            f32x4 mv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            r.p = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + o));
             if constexpr (!FRESH) {
-                mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mw + o));
-                vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vw + o));
+                r.m = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mw + o));
+                r.v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vw + o));
             }
+        }
+    }
+    __device__ __forceinline__ void finish4(Row& r, float4 g, int m, int n) const {
+        if (m >= M || n > N) return;
+        if (vec(m, n)) {
+            const size_t o = (size_t)m * N + n;
             const float* gg = &g.x;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float gr = gg[j] + wd * pv[j];
-                mv[j] = beta1 * mv[j] + (1.f - beta1) * gr;
-                vv[j] = beta2 * vv[j] + (1.f - beta2) * gr * gr;
-                pv[j] -= step * (mv[j] / (sqrtf(vv[j]) * isb2 + eps));
+                const float gr = gg[j] + wd * r.p[j];
+                r.m[j] = beta1 * r.m[j] + (1.f - beta1) * gr;
+                r.v[j] = beta2 * r.v[j] + (1.f - beta2) * gr * gr;
+                r.p[j] -= step * (r.m[j] / (sqrtf(r.v[j]) * isb2 + eps));
             }
-            __builtin_nontemporal_store(pv, reinterpret_cast<f32x4*>(w + o));
-            __builtin_nontemporal_store(mv, reinterpret_cast<f32x4*>(mw + o));
-            __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(vw + o));
+            __builtin_nontemporal_store(r.p, reinterpret_cast<f32x4*>(w + o));
+            __builtin_nontemporal_store(r.m, reinterpret_cast<f32x4*>(mw + o));
+            __builtin_nontemporal_store(r.v, reinterpret_cast<f32x4*>(vw + o));
         } else {
             const float gv[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
@@ -589,21 +599,29 @@ struct EpiWgradSgdm {
         *m = mv;
         *p = pv - lr * mv;
     }
-    __device__ __forceinline__ void store4(float4 g, int m, int n) const {
-        if (m >= M || n > N) return;
-        if (n + 3 < N && (N & 3) == 0) {
+    static constexpr int BATCH = 8;
+    struct Row { f32x4 p, m; };
+    __device__ __forceinline__ bool vec(int m, int n) const { return m < M && n + 3 < N && (N & 3) == 0; }
+    __device__ __forceinline__ void load4(Row& r, int m, int n) const {
+        r.p = f32x4{0.f, 0.f, 0.f, 0.f}; r.m = r.p;
+        if (vec(m, n)) {
             const size_t o = (size_t)m * N + n;
-            f32x4 pv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + o));
-            f32x4 mv = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (!FRESH) mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mw + o));
+            r.p = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + o));
+            if constexpr (!FRESH) r.m = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mw + o));
+        }
+    }
+    __device__ __forceinline__ void finish4(Row& r, float4 g, int m, int n) const {
+        if (m >= M || n > N) return;
+        if (vec(m, n)) {
+            const size_t o = (size_t)m * N + n;
             const float* gg = &g.x;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                mv[j] = momentum * mv[j] + (gg[j] + wd * pv[j]);
-                pv[j] -= lr * mv[j];
+                r.m[j] = momentum * r.m[j] + (gg[j] + wd * r.p[j]);
+                r.p[j] -= lr * r.m[j];
             }
-            __builtin_nontemporal_store(pv, reinterpret_cast<f32x4*>(w + o));
-            __builtin_nontemporal_store(mv, reinterpret_cast<f32x4*>(mw + o));
+            __builtin_nontemporal_store(r.p, reinterpret_cast<f32x4*>(w + o));
+            __builtin_nontemporal_store(r.m, reinterpret_cast<f32x4*>(mw + o));
         } else {
             const float gv[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll

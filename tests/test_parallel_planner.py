@@ -85,3 +85,17 @@ def test_exchange_time_model_is_per_link():
     t = estimate_exchange_seconds(plans[0], row_bytes, world)
     assert 0.2e-4 < t < 1e-4            # ~26 MB all-reduce over 7 links: tens of microseconds, not milliseconds
     assert estimate_exchange_seconds(plans[0], row_bytes, 1) == 0.0
+
+
+def test_inplace_reduce_is_a_gpu_only_path():
+    """On the CPU the in-place FedAvg declines (nothing touched) and the two-slab reference path is used."""
+    import torch
+    from p2pfl_amd.runtime.aggregation import build_plan, fedavg_reference, inplace_supported, run_plan_inplace
+    slab = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+    plan = build_plan([([0, 1], [1.0, 3.0], [2])])
+    assert not inplace_supported(slab, 0)
+    before = slab.clone()
+    assert run_plan_inplace(slab, None, plan) is False and torch.equal(slab, before)
+    out = slab.clone()
+    fedavg_reference(slab, None, out, plan)
+    assert torch.allclose(out[2], 0.25 * slab[0] + 0.75 * slab[1]) and torch.equal(out[:2], slab[:2])

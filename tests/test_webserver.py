@@ -239,6 +239,59 @@ def test_pages_render_with_bundled_scripts(web):
     assert b"lineChart" in c.get(f"/scenario/{name}/statistics/").data
 
 
+def test_designer_scripts_parse_and_graph_editing_works(web, tmp_path):
+    """The designer's scripts are syntactically valid JavaScript and the topology widget grows / shrinks / projects a
+    federation correctly (run under node with a stub canvas; skipped where node is not installed)."""
+    import re
+    import shutil
+    import subprocess
+    node = shutil.which("node")
+    if node is None:
+        pytest.skip("node is not installed")
+    appmod, c, tmp = web
+    _login(c)
+    page = c.get("/scenario/deployment/").data.decode()
+    for must in ("view3d", "mode_expert", "ne_add", "ne_del", "adj_table", "save_json", "load_json", 'id="confirm"'):
+        assert must in page
+    scripts = re.findall(r"<script>(.*?)</script>", page, flags=re.S)
+    assert scripts
+    inline = tmp_path / "inline.js"
+    inline.write_text("\n".join(scripts))
+    graph_js = os.path.join(os.path.dirname(appmod.__file__), "static", "js", "graph.js")
+    for f in (str(inline), graph_js, os.path.join(os.path.dirname(graph_js), "charts.js")):
+        r = subprocess.run([node, "--check", f], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    driver = tmp_path / "drive.js"
+    driver.write_text("""
+const ctx = new Proxy({}, {get: (t, k) => (k in t ? t[k] : () => {}), set: (t, k, v) => { t[k] = v; return true; }});
+global.window = global;
+const canvas = {width: 520, height: 520, getContext: () => ctx, addEventListener: () => {}, getBoundingClientRect: () => ({left: 0, top: 0, width: 520, height: 520})};
+global.window.addEventListener = () => {};
+require(process.argv[2]);
+let changes = 0;
+const g = new TopologyGraph(canvas, {editable: true, onChange: () => changes++});
+g.setMatrix(TopologyGraph.generate('ring', 5, 7), ['aggregator', 'trainer', 'trainer', 'trainer', 'trainer']);
+const j = g.addNode(2, 'trainer');
+let m = g.matrix();
+if (j !== 5 || m.length !== 6 || m[5][2] !== 1 || m[2][5] !== 1 || m[5].reduce((a, b) => a + b) !== 1) throw new Error('addNode');
+if (!g.removeNode(0) || g.matrix().length !== 5 || g.roles.length !== 5 || g.roles[0] !== 'trainer') throw new Error('removeNode');
+m = g.matrix();
+for (let a = 0; a < 5; a++) for (let b = 0; b < 5; b++) if (m[a][b] !== m[b][a]) throw new Error('symmetry');
+g.set3d(true, false);
+const p = g._proj(1);
+if (!(isFinite(p[0]) && isFinite(p[1]) && p[2] > 0.5 && p[2] < 2)) throw new Error('projection');
+g.linkDistance = 0.5; g.draw(); g.set3d(false, false);
+const q = g._proj(1);
+if (Math.abs(q[0] - (260 + (g.pos[1][0] - 260) * 0.5)) > 1e-9) throw new Error('distance scaling');
+while (g.n > 2) g.removeNode(g.n - 1);
+if (g.removeNode(0)) throw new Error('a federation keeps two nodes');
+if (changes < 4) throw new Error('onChange');
+console.log('ok');
+""")
+    r = subprocess.run([node, str(driver), graph_js], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
+
+
 def test_remove_refuses_dot_names_and_keeps_the_roots(web):
     """/scenario/%2e/remove used to rmtree the whole config and log directories (".." their parents)."""
     appmod, c, tmp = web

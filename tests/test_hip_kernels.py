@@ -507,7 +507,7 @@ def test_fedavg_groups(n_local, n_remote, P):
     assert torch.allclose(out, ref, atol=1e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("n_local,n_remote,P", [(5, 0, 1024), (12, 7, 4100), (100, 0, 50_000), (100, 100, 8192), (300, 40, 2052), (600, 0, 1024)])
+@pytest.mark.parametrize("n_local,n_remote,P", [(5, 0, 1024), (12, 7, 4100), (100, 0, 50_000), (100, 100, 8192), (300, 40, 2052), (460, 40, 1024), (600, 0, 1024)])
 def test_fedavg_inplace_matches_two_slab_reduce(n_local, n_remote, P):
     """In-place reduce (every source row read once into LDS, destinations overwritten) == the reference into a second
     slab; rows no group writes keep their content; more rows than the LDS pool holds -> declined, nothing touched."""

@@ -9,11 +9,19 @@ so model exchange stays "pass a row index" / one RCCL all-to-all of rows, and Fe
 kernel (``csrc/fedavg.hip``), exactly as for the spec models. Integer buffers (``num_batches_tracked``) stay
 node-local.
 
+Client-batched execution: the slab IS a stack of the K models (column range of an entry = ``[K, *shape]``), so one
+``torch.func.vmap`` over ``functional_call`` runs a training step of ALL co-resident nodes at once - a batched GEMM per
+linear layer, a grouped convolution per conv layer, BatchNorm with per-node statistics - instead of K Python-looped
+steps of launch-bound kernels, and ONE optimizer over the stacked tensors replaces K (Adam / SGD are element-wise, so
+it is the same arithmetic per node). Families whose step vmap cannot express fall back to the per-node loop.
+
 Reference behaviour kept: a new optimizer per round (lightninglearner.py:148-160), per-epoch validation, evaluation
 before training, loss / confusion-matrix metrics for classifiers, loss only for the others.
 """
 from __future__ import annotations
 
+import logging
+import os
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence
@@ -75,11 +83,28 @@ class StateLayout(ParamLayout):
         return {}
 
 
+class _LossCall(torch.nn.Module):
+    """``forward`` = the wrapped module's ``training_loss`` (``functional_call`` only calls ``forward``)."""
+
+    def __init__(self, m: torch.nn.Module):
+        super().__init__()
+        self.m = m
+
+    def forward(self, x, y):
+        loss, pred = self.m.training_loss(x, y)
+        if pred is None:
+            pred = torch.zeros(x.shape[0], dtype=torch.long, device=x.device)
+        return loss, pred
+
+
 class ModuleEngine(ShardEngine):
-    """K independent ``nn.Module`` replicas on one device whose float state aliases the slab rows."""
+    """K independent ``nn.Module`` replicas on one device whose float state aliases the slab rows.
+
+    ``batched``: train / evaluate all K replicas per step through ``torch.func.vmap`` (default; None = unless
+    ``P2PFL_MODULE_VMAP=0``). The per-node loop remains as the fallback and as the oracle of the batched path."""
 
     def __init__(self, spec: ModuleSpec, n_clients: int, device="cpu", batch_size: int = 32, seed: int = 0,
-                 persist_optimizer: bool = False, client_offset: int = 0):
+                 persist_optimizer: bool = False, client_offset: int = 0, batched: Optional[bool] = None):
         self.spec = spec
         self.K = int(n_clients)
         self.device = torch.device(device)
@@ -107,6 +132,17 @@ class ModuleEngine(ShardEngine):
                 view.copy_(t.detach())
                 t.data = view                                    # parameter / buffer now lives in the slab row
         self.optims = None
+        if batched is None:
+            batched = os.environ.get("P2PFL_MODULE_VMAP", "1") != "0"
+        self.batched = bool(batched) and self.K > 1
+        self._stack = None            # name -> [K, *shape] view of the slab (floats) / stacked integer buffers
+        self._stack_opt = None
+        if self.batched:
+            try:
+                self._build_stack()
+            except Exception as exc:                      # noqa: BLE001 - any family vmap cannot take: per-node loop
+                logging.warning("[ModuleEngine] %s: client-batched execution unavailable (%s); per-node loop", spec.name, exc)
+                self.batched = False
 
     # ------------------------------------------------------------------ parameters
     def init_params(self, seed: Optional[int] = None, identical: bool = True) -> None:
@@ -146,9 +182,141 @@ class ModuleEngine(ShardEngine):
         self.val_x, self.val_y = put(val_x, val_y)
         self.test_x, self.test_y = put(test_x, test_y)
 
+    # ------------------------------------------------------------------ client-batched execution (torch.func)
+    def _build_stack(self) -> None:
+        m0 = self.modules[0]
+        pnames = {n for n, _ in m0.named_parameters()}
+        stack: Dict[str, torch.Tensor] = {}
+        for s_ in self.layout.slots:
+            t = self.params[:, s_.offset:s_.offset + s_.numel].view(self.K, *s_.shape)
+            if s_.name in pnames:
+                t.requires_grad_(True)                   # a leaf that IS the slab's column range
+            stack["m." + s_.name] = t
+        # integer buffers (BatchNorm's num_batches_tracked) are not in the slab: one stacked tensor per entry whose
+        # rows the replicas' own buffers alias from now on
+        for name in self.layout.int_keys:
+            own = [dict(m.named_buffers())[name] for m in self.modules]
+            st = torch.stack([b.detach() for b in own])
+            for k, b in enumerate(own):
+                b.data = st[k]
+            stack["m." + name] = st
+        self._stack = stack
+        self._param_keys = ["m." + n for n, _ in m0.named_parameters()]
+        # floating-point buffers (BatchNorm running statistics): vmap's batch-norm rule drops the in-place update of a
+        # NON-contiguous batched buffer (a slab column range has the row stride of the slab), so a pass works on
+        # contiguous copies and writes them back (see _state / _writeback)
+        self._fbuf_keys = ["m." + s_.name for s_ in self.layout.slots if s_.name not in pnames]
+        self._call = _LossCall(m0)
+        from torch.func import functional_call, vmap
+
+        def one(state, x, y):
+            return functional_call(self._call, state, (x, y))
+        self._vstep = vmap(one, in_dims=(0, 0, 0), randomness="different")
+
+    def _state(self) -> Dict[str, torch.Tensor]:
+        st = dict(self._stack)
+        for k in self._fbuf_keys:
+            st[k] = self._stack[k].detach().contiguous().clone()
+        return st
+
+    def _writeback(self, st: Dict[str, torch.Tensor]) -> None:
+        with torch.no_grad():
+            for k in self._fbuf_keys:
+                self._stack[k].copy_(st[k])
+
+    def _stacked_optimizer(self):
+        """The replicas' optimizer, built once over the stacked tensors (same class, same groups and hyper-parameters
+        as ``configure_optimizers`` of one replica)."""
+        m0 = self.modules[0]
+        opt0 = m0.configure_optimizers()
+        if not isinstance(opt0, torch.optim.Optimizer):
+            raise TypeError("configure_optimizers() did not return a plain optimizer")
+        name_of = {id(p): "m." + n for n, p in m0.named_parameters()}
+        groups = []
+        for g in opt0.param_groups:
+            ng = {k: v for k, v in g.items() if k != "params"}
+            ng["params"] = [self._stack[name_of[id(p)]] for p in g["params"]]
+            groups.append(ng)
+        return type(opt0)(groups)
+
+    def _metrics(self, phase: str, losses, preds, yb, nb: int) -> None:
+        st, C, K = self.stats[phase], self.C, self.K
+        st.loss_sum += losses.detach().float() * nb
+        st.count += nb
+        if self.classifier:
+            pred = preds.long().clamp(0, C - 1)
+            yc = yb.long().clamp(0, C - 1)
+            st.correct += (pred == yc).sum(dim=1).to(torch.int32)
+            off = torch.arange(K, device=self.device).view(K, 1) * (C * C)
+            st.confusion.view(-1).index_add_(0, (off + yc * C + pred).reshape(-1),
+                                             torch.ones(K * nb, dtype=torch.int32, device=self.device))
+
+    def _phase_batched(self, x, y, phase: str, train: bool, optim=None, order=None) -> None:
+        """One pass over [K, n, ...] data for all replicas at once; ``order`` [K, n] sample order (training)."""
+        state = self._state()
+        try:
+            self._phase_batched_inner(state, x, y, phase, train, optim, order)
+        finally:
+            if train:
+                self._writeback(state)
+
+    def _phase_batched_inner(self, state, x, y, phase: str, train: bool, optim, order) -> None:
+        n = x.shape[1]
+        m0 = self.modules[0]
+        m0.train(train)
+        kar = torch.arange(self.K, device=self.device).view(self.K, 1)
+        for s in range(0, n, self.B):
+            nb = min(self.B, n - s)
+            if train and nb < 2:
+                continue                                     # BatchNorm cannot train on a single sample
+            if order is not None:
+                idx = order[:, s:s + nb]
+                xb, yb = x[kar, idx], y[kar, idx]
+            else:
+                xb, yb = x[:, s:s + nb], y[:, s:s + nb]
+            if self.classifier:
+                yb = yb.long()
+            if train:
+                if self.spec.augment is not None:
+                    xb = self.spec.augment(xb.reshape(self.K * nb, *xb.shape[2:])).reshape(xb.shape)
+                losses, preds = self._vstep(state, xb, yb)
+                optim.zero_grad(set_to_none=True)
+                losses.sum().backward()
+                optim.step()
+            else:
+                with torch.no_grad():
+                    losses, preds = self._vstep(state, xb, yb)
+            self._metrics(phase, losses, preds, yb, nb)
+
+    def _fit_batched(self, epochs: int, active) -> Dict:
+        if self._stack_opt is None or not self.persist_optimizer:
+            self._stack_opt = self._stacked_optimizer()
+        saved = None
+        if active is not None and not bool(torch.as_tensor(active).all()):
+            inactive = (~torch.as_tensor(active, dtype=torch.bool)).nonzero().flatten().to(self.device)
+            ints = {k: self._stack["m." + k][inactive].clone() for k in self.layout.int_keys}
+            saved = (inactive, self.params[inactive].clone(), ints)
+        perms = self._epoch_perms(epochs).to(self.device).long()
+        n = self.train_x.shape[1]
+        out = {}
+        for e in range(epochs):
+            self.stats["Train"].zero_(); self.stats["Validation"].zero_()
+            self._phase_batched(self.train_x, self.train_y, "Train", True, self._stack_opt, perms[e, :, :n])
+            if self.val_x is not None:
+                self._phase_batched(self.val_x, self.val_y, "Validation", False)
+            out = {"Train": self.stats["Train"].summary(), "Validation": self.stats["Validation"].summary()}
+        if saved is not None:                                # nodes that sat the round out keep their model
+            with torch.no_grad():
+                self.params[saved[0]] = saved[1]
+                for k, v in saved[2].items():
+                    self._stack["m." + k][saved[0]] = v
+        self.opt_steps += epochs * self.steps_per_epoch()
+        return out
+
     # ------------------------------------------------------------------ training / evaluation
     def reset_optimizer(self) -> None:
         self.optims = [m.configure_optimizers() for m in self.modules]
+        self._stack_opt = None
         self.opt_steps = 0
 
     def _run_phase(self, k, x, y, phase, train, optim=None, order=None) -> None:
@@ -180,6 +348,16 @@ class ModuleEngine(ShardEngine):
                 st.confusion[k].view(-1).index_add_(0, yc * C + pred, torch.ones_like(pred, dtype=torch.int32))
 
     def fit(self, epochs, active=None):
+        if self.batched:
+            try:
+                return self._fit_batched(epochs, active)
+            except (RuntimeError, NotImplementedError, TypeError) as exc:
+                if self.opt_steps > 0 or os.environ.get("P2PFL_MODULE_VMAP_STRICT"):
+                    raise                                     # it worked before: a real error, not an unsupported op
+                logging.warning("[ModuleEngine] %s: client-batched step failed (%s); per-node loop from here on",
+                                self.spec.name, exc)
+                self.batched = False
+                self._perm_calls = max(self._perm_calls - 1, 0)
         if self.optims is None or not self.persist_optimizer:
             self.reset_optimizer()
         perms = self._epoch_perms(epochs).to(self.device).long()
@@ -201,6 +379,17 @@ class ModuleEngine(ShardEngine):
 
     def evaluate(self):
         self.stats["Test"].zero_()
+        if self.batched:
+            try:
+                self._phase_batched(self.test_x, self.test_y, "Test", False)
+                return self.stats["Test"].summary()
+            except (RuntimeError, NotImplementedError, TypeError) as exc:
+                if self.opt_steps > 0 or os.environ.get("P2PFL_MODULE_VMAP_STRICT"):
+                    raise
+                logging.warning("[ModuleEngine] %s: client-batched evaluation failed (%s); per-node loop from here on",
+                                self.spec.name, exc)
+                self.batched = False
+                self.stats["Test"].zero_()
         for k in range(self.K):
             self.modules[k].eval()
             self._run_phase(k, self.test_x[k], self.test_y[k], "Test", False)

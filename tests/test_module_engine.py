@@ -156,3 +156,92 @@ def test_two_ranks_exchange_rows_of_module_state():
     for i in range(6):
         assert torch.allclose(got[i], rows[[(i - 1) % 6, i, (i + 1) % 6]].mean(0), atol=1e-6)
     assert out[0][1] and out[1][1] and out[0][2] == 2 and out[1][2] == 2
+
+
+def _pair(ds, model, K=3, n=24, B=8, **kw):
+    probe = build_dataset_and_model(ds, model, 0, 20)[0]
+    spec = ModuleSpec(f"{ds}-{model}", lambda: build_model(ds, model), probe.num_classes, tuple(probe.input_shape))
+    shards = [build_dataset_and_model(ds, model, i, 20)[0] for i in range(K)]
+    data = [torch.stack([s.tensors()[j][:n] for s in shards]) for j in range(6)]
+    engines = []
+    for batched in (False, True):
+        eng = ModuleEngine(spec, K, "cpu", seed=1, batched=batched, batch_size=B, **kw)
+        eng.set_data(*data)
+        eng.init_params(identical=False)
+        for m in eng.modules:
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = 0.0                          # the two paths draw their masks from different streams
+        engines.append(eng)
+    return engines
+
+
+@pytest.mark.parametrize("ds,model", [("SYSCALL", "MLP"), ("SYSCALL", "SVM"), ("SYSCALL", "Autoencoder"), ("WADI", "MLP")])
+def test_client_batched_step_matches_the_per_node_loop(ds, model, monkeypatch):
+    """torch.func.vmap over all replicas (one stacked optimizer) == K Python-looped replicas with K optimizers:
+    weights, BatchNorm running statistics (kept in the slab), integer buffers, metrics."""
+    monkeypatch.setenv("P2PFL_MODULE_VMAP_STRICT", "1")
+    loop, vm = _pair(ds, model)
+    assert vm.batched and not loop.batched
+    e0, e1 = loop.evaluate(), vm.evaluate()
+    assert torch.allclose(e0["loss"], e1["loss"], atol=1e-5) and torch.equal(e0["count"], e1["count"])
+    active = torch.tensor([True, False, True])
+    before = vm.params[1].clone()
+    o0, o1 = loop.fit(2, active=active), vm.fit(2, active=active)
+    assert vm.batched, "the batched path must not have fallen back"
+    assert torch.allclose(o0["Train"]["loss"][active], o1["Train"]["loss"][active], atol=1e-4)
+    assert torch.equal(o0["Train"]["confusion"][active], o1["Train"]["confusion"][active])
+    assert torch.equal(vm.params[1], before) and torch.equal(loop.params[1], before)      # sat the round out
+    for s in loop.layout.slots:
+        a, b = loop.layout.view(loop.params, s.name), vm.layout.view(vm.params, s.name)
+        if "batchnorm1.weight" in loop.layout.by_name:
+            # a bias in front of BatchNorm has a zero true gradient: Adam turns rounding noise into +-lr steps, and
+            # the running mean behind it averages that wandering bias in. Neither changes what the model computes
+            # in training mode; the evaluation losses below cover their net effect.
+            if s.name in ("l1.bias", "l2.bias", "batchnorm1.running_mean", "batchnorm2.running_mean"):
+                continue
+        assert torch.allclose(a, b, atol=2e-4), s.name
+    for k in range(3):
+        for (n0, b0), (_, b1) in zip(loop.modules[k].named_buffers(), vm.modules[k].named_buffers()):
+            if not torch.is_floating_point(b0):
+                assert torch.equal(b0, b1), n0          # num_batches_tracked advanced alike (not for the idle node)
+    t0, t1 = loop.evaluate(), vm.evaluate()
+    assert torch.allclose(t0["loss"], t1["loss"], atol=1e-3)
+    # the replicas still see the slab: an aggregation result written into a row is what they compute with
+    vm.params[1].copy_(vm.params[0])
+    x = vm.test_x[0][:8]
+    vm.modules[0].eval(); vm.modules[1].eval()
+    assert torch.equal(vm.modules[0](x), vm.modules[1](x))
+
+
+def test_client_batched_falls_back_when_vmap_cannot_express_the_step():
+    """A family with data-dependent Python control flow in its loss trains through the per-node loop."""
+    class Odd(torch.nn.Module):
+        is_classifier = True
+
+        def __init__(self):
+            super().__init__()
+            self.l = torch.nn.Linear(4, 3)
+
+        def forward(self, x):
+            return self.l(x)
+
+        def training_loss(self, x, y):
+            out = self(x)
+            scale = 2.0 if float(out.sum()) > 0 else 1.0           # .item(): not traceable by vmap
+            return torch.nn.functional.cross_entropy(out, y) * scale, out.detach().argmax(1)
+
+        def configure_optimizers(self):
+            return torch.optim.SGD(self.parameters(), lr=0.1)
+    spec = ModuleSpec("odd", Odd, 3, (4,))
+    eng = ModuleEngine(spec, 2, "cpu", batch_size=4)
+    assert eng.batched
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.randn(2, 8, 4, generator=g), torch.randint(0, 3, (2, 8), generator=g)
+    eng.set_data(x, y, x, y, x, y)
+    before = eng.params.clone()
+    l0 = eng.evaluate()["loss"]
+    assert not eng.batched                                          # evaluation already declined
+    out = eng.fit(3)
+    assert out["Train"]["count"].tolist() == [8, 8] and not torch.equal(before, eng.params)
+    assert (eng.evaluate()["loss"] < l0 * 2.0 + 1e-6).all()

@@ -1,8 +1,8 @@
-"""bf16-MFMA engine against the fp32 eager engine over whole federations: per-round test loss / accuracy of both.
+"""HIP engine (default precision policy, or P2PFL_PRECISION) against the fp32 eager engine over whole federations: per-round test loss / accuracy of both.
 
 usage (GPU box): python tools/convergence_check.py [rounds] [nodes] [model ...] > profiles/<name>.json
-Same topology, data shards, initial weights and shuffles for both engines; differences come from bf16 operand
-rounding (fp32 accumulation, fp32 master weights / optimizer state) and summation order only.
+Same topology, data shards, initial weights and shuffles for both engines; differences come from the summation
+order (fp32 policies) or from bf16 operand rounding (bf16 policy: fp32 accumulation, master weights, optimizer state).
 """
 import json
 import os

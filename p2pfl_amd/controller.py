@@ -311,13 +311,14 @@ class Controller:
         pair = (p0["data_args"]["dataset"], p0["model_args"]["model"])
         homogeneous = all((p["data_args"]["dataset"], p["model_args"]["model"]) == pair for p in self.config.participants)
         if self.engine == "process":
-            if homogeneous and pair in BATCHED_PAIRS and any(
+            if homogeneous and any(
                     p["device_args"].get("accelerator") in ("gpu", "auto") for p in self.config.participants):
                 # compatibility path: every OS process drives its own one-client engine (K = 1 launches, a host
                 # round trip per payload, the TCP pacing constants) - two orders of magnitude below the batched path
                 logging.warning("--engine process with a GPU accelerator runs ONE client per kernel launch and per "
-                                "process; %s / %s is supported by the client-batched runtime: drop --engine process "
-                                "(or pass --engine batched) to host all %d nodes in one process per GPU",
+                                "process; %s / %s runs client-batched in the one-process-per-GPU runtime (hand-written "
+                                "kernels for the MNIST / FEMNIST models, torch.func.vmap steps for the others): pass "
+                                "--engine batched to host all %d nodes in one process per GPU",
                                 pair[0], pair[1], self.n_nodes)
             return False
         if self.engine == "batched":

@@ -125,15 +125,28 @@ def inplace_supported(slab: torch.Tensor, n_remote: int) -> bool:
     return int(hip.load().p2pfl_fedavg_inplace_chunk(int(slab.shape[0]) + int(n_remote))) > 0
 
 
+def single_group_inplace(slab: torch.Tensor, plan: AggregationPlan) -> bool:
+    """ONE group (a star / fully connected federation: everybody gets the same average) can always be reduced in
+    place by the plain kernel: a thread reads all sources of its columns before it writes any destination, and no
+    other thread touches those columns."""
+    import os
+    return slab.is_cuda and plan.n_groups == 1 and not os.environ.get("P2PFL_FEDAVG_TWO_SLABS")
+
+
 def run_plan_inplace(slab: torch.Tensor, remote: Optional[torch.Tensor], plan: AggregationPlan,
                      n_remote: int = 0) -> bool:
     """Execute a plan whose destination slab IS the source slab (``csrc/fedavg.hip``: every source row is read once,
     destinations are overwritten in place; rows no group writes keep their content). False: not applicable."""
     if plan.n_groups == 0:
         return True
+    rem = remote[:n_remote] if (remote is not None and n_remote > 0) else None
+    if single_group_inplace(slab, plan):
+        from ..ops import hip
+        p = plan if plan.src_ptr.is_cuda else plan.to(slab.device)
+        hip.fedavg(slab, rem, slab, p.src_ptr, p.src_row, p.src_w, p.dst_ptr, p.dst_row)
+        return True
     if not inplace_supported(slab, n_remote):
         return False
     from ..ops import hip
     p = plan if plan.src_ptr.is_cuda else plan.to(slab.device)
-    rem = remote[:n_remote] if (remote is not None and n_remote > 0) else None
     return hip.fedavg_inplace(slab, rem, p.src_ptr, p.src_row, p.src_w, p.dst_ptr, p.dst_row)

@@ -42,7 +42,8 @@ from ..models.specs import ModelSpec
 from ..parallel.collectives import DeviceExchange
 from ..parallel.planner import link_key, partition_nodes, plan_exchange  # noqa: F401  (re-exported)
 from ..role import Role, default_roles
-from .aggregation import AggregationPlan, build_plan, inplace_supported, run_plan, run_plan_inplace
+from .aggregation import (AggregationPlan, build_plan, inplace_supported, run_plan, run_plan_inplace,
+                          single_group_inplace)
 from .engine import ShardEngine, make_engine
 from .membership import VirtualMembership
 
@@ -263,7 +264,7 @@ class BatchedFederation:
         cached, all_covered = self._plan()
         if cached is None:
             return 0
-        if cached[0] == "rows" and inplace_supported(eng.params, cached[4]):
+        if cached[0] == "rows" and (inplace_supported(eng.params, cached[4]) or single_group_inplace(eng.params, cached[3])):
             # one slab: the reduce reads every row once and overwrites the destinations in place (no second slab,
             # no copy back into the slab the captured graphs point at; uncovered rows keep their model by themselves)
             _, send_lists, recv_lists, plan, n_recv = cached
@@ -333,8 +334,8 @@ class BatchedFederation:
         if hasattr(self.engine, "prepare"):
             self.engine.prepare(self.epochs)
         cached, _ = self._plan()
-        if self.virtual_devices > 1 or cached is None or not (cached[0] == "rows" and
-                                                             inplace_supported(self.engine.params, cached[4])):
+        if self.virtual_devices > 1 or cached is None or not (cached[0] == "rows" and (
+                inplace_supported(self.engine.params, cached[4]) or single_group_inplace(self.engine.params, cached[3]))):
             self.engine.alt_slab()       # (the in-place reduce needs no second slab)
 
     def _plan(self):

@@ -542,6 +542,20 @@ def test_fedavg_inplace_matches_two_slab_reduce(n_local, n_remote, P):
     assert torch.equal(local[untouched], before[untouched])
 
 
+def test_fedavg_single_group_reduces_in_place_whatever_the_row_count():
+    """A star / fully connected federation is ONE group: in place with the plain kernel, for 1000 rows too."""
+    from p2pfl_amd.runtime.aggregation import build_plan, fedavg_reference, run_plan_inplace
+    gen = torch.Generator().manual_seed(3)
+    slab = torch.randn(1000, 512, generator=gen).to(DEV)
+    w = torch.randint(1, 600, (1000,), generator=gen).tolist()
+    plan = build_plan([(list(range(1000)), w, list(range(1, 1000)))])     # row 0 (say: a dead node) keeps its model
+    ref = slab.clone()
+    fedavg_reference(slab, None, ref, plan)
+    row0 = slab[0].clone()
+    assert run_plan_inplace(slab, None, plan)
+    assert torch.allclose(slab, ref, atol=1e-5, rtol=1e-5) and torch.equal(slab[0], row0)
+
+
 def test_aes128_ecb_known_answer_and_roundtrip():
     h = hip()
     from p2pfl_amd.utils.aes import expand_key, ecb_host

@@ -137,6 +137,17 @@ class ModuleEngine(ShardEngine):
         self.batched = bool(batched) and self.K > 1
         self._stack = None            # name -> [K, *shape] view of the slab (floats) / stacked integer buffers
         self._stack_opt = None
+        # hipGraph replay of a whole batched pass (an epoch of steps incl. backward and optimizer, or an evaluation
+        # pass): small families are launch-bound even client-batched (50 SYSCALL MLPs: ~50 kernels of microseconds per
+        # step). A pass runs eagerly the first time (lazy initialisation, MIOpen search), is captured at its second
+        # occurrence and replayed from then on. Not with a host-side augmentation hook (its random draws would be
+        # baked into the graph). P2PFL_MODULE_GRAPH=0 keeps the passes eager.
+        self.use_graph = (self.device.type == "cuda" and spec.augment is None
+                          and os.environ.get("P2PFL_MODULE_GRAPH", "1") != "0")
+        self._graphs: Dict[tuple, object] = {}
+        self._seen: set = set()
+        self._gstate = None
+        self._perm_static = None
         if self.batched:
             try:
                 self._build_stack()
@@ -181,6 +192,11 @@ class ModuleEngine(ShardEngine):
         self.train_x, self.train_y = put(train_x, train_y)
         self.val_x, self.val_y = put(val_x, val_y)
         self.test_x, self.test_y = put(test_x, test_y)
+        if getattr(self, "_graphs", None):
+            torch.cuda.synchronize(self.device)
+            self._graphs.clear()
+        if hasattr(self, "_seen"):
+            self._seen.clear()
 
     # ------------------------------------------------------------------ client-batched execution (torch.func)
     def _build_stack(self) -> None:
@@ -235,9 +251,24 @@ class ModuleEngine(ShardEngine):
         groups = []
         for g in opt0.param_groups:
             ng = {k: v for k, v in g.items() if k != "params"}
+            if "capturable" in ng and self.use_graph:
+                ng["capturable"] = True                     # step counter on the device: the step can live in a graph
             ng["params"] = [self._stack[name_of[id(p)]] for p in g["params"]]
             groups.append(ng)
         return type(opt0)(groups)
+
+    def _fresh_optimizer(self):
+        """A new optimizer per round (reference lightninglearner.py:148-160). With graph replay the optimizer OBJECT
+        has to stay (the captured steps hold its state tensors): its state - moments, momentum buffers, the device
+        step counter - is zeroed in place instead, which is what a new Adam / SGD(dampening 0) starts from."""
+        if self._stack_opt is not None and self.use_graph:
+            with torch.no_grad():
+                for st in self._stack_opt.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
+            return self._stack_opt
+        return self._stacked_optimizer()
 
     def _metrics(self, phase: str, losses, preds, yb, nb: int) -> None:
         st, C, K = self.stats[phase], self.C, self.K
@@ -253,12 +284,54 @@ class ModuleEngine(ShardEngine):
 
     def _phase_batched(self, x, y, phase: str, train: bool, optim=None, order=None) -> None:
         """One pass over [K, n, ...] data for all replicas at once; ``order`` [K, n] sample order (training)."""
+        if self.use_graph and self._phase_graphed(x, y, phase, train, optim, order):
+            return
         state = self._state()
         try:
             self._phase_batched_inner(state, x, y, phase, train, optim, order)
         finally:
             if train:
                 self._writeback(state)
+
+    def _phase_graphed(self, x, y, phase: str, train: bool, optim, order) -> bool:
+        """Replay (or capture at the second occurrence of) this pass as one hipGraph; False: run it eagerly."""
+        key = (phase, train, x.data_ptr(), tuple(x.shape), None if optim is None else id(optim))
+        if key not in self._seen:                  # first occurrence: eager (warm-up of everything lazy)
+            self._seen.add(key)
+            return False
+        if self._gstate is None:                   # static tensors the graphs read / update: BN statistics, shuffles
+            self._gstate = dict(self._stack)
+            for k in self._fbuf_keys:
+                self._gstate[k] = self._stack[k].detach().contiguous().clone()
+        with torch.no_grad():
+            for k in self._fbuf_keys:
+                self._gstate[k].copy_(self._stack[k])
+        order_static = None
+        if order is not None:
+            if self._perm_static is None or self._perm_static.shape != order.shape:
+                self._perm_static = torch.empty_like(order)
+                self._graphs = {k: g for k, g in self._graphs.items() if not k[1]}      # training graphs read it
+            self._perm_static.copy_(order)
+            order_static = self._perm_static
+        g = self._graphs.get(key)
+        if g is None:
+            try:
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._phase_batched_inner(self._gstate, x, y, phase, train, optim, order_static)
+            except Exception as exc:  # noqa: BLE001 - a family / optimizer that cannot be captured stays eager
+                logging.warning("[ModuleEngine] %s: hipGraph capture of the %s pass failed (%s); eager from here on",
+                                self.spec.name, phase, str(exc).splitlines()[0] if str(exc) else type(exc).__name__)
+                self.use_graph = False
+                self._graphs.clear()
+                torch.cuda.synchronize(self.device)
+                return False
+            self._graphs[key] = g
+        g.replay()
+        if train:
+            self._writeback(self._gstate)
+        return True
 
     def _phase_batched_inner(self, state, x, y, phase: str, train: bool, optim, order) -> None:
         n = x.shape[1]
@@ -290,7 +363,7 @@ class ModuleEngine(ShardEngine):
 
     def _fit_batched(self, epochs: int, active) -> Dict:
         if self._stack_opt is None or not self.persist_optimizer:
-            self._stack_opt = self._stacked_optimizer()
+            self._stack_opt = self._fresh_optimizer()
         saved = None
         if active is not None and not bool(torch.as_tensor(active).all()):
             inactive = (~torch.as_tensor(active, dtype=torch.bool)).nonzero().flatten().to(self.device)

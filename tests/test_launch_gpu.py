@@ -53,3 +53,47 @@ def test_scenario_on_the_hip_engine(tmp_path, dataset, model, federation, topolo
     if dataset == "MNIST":       # synthetic MNIST-shaped shards are learnable: resumed weights evaluate well at once
         first_eval = [l for l in open(logs / "participant_1.log").read().splitlines() if "round 2 " in l][0]
         assert float(first_eval.split("test_acc ")[1].split()[0]) > 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ds,model", [("SYSCALL", "MLP"), ("SYSCALL", "SVM"), ("WADI", "MLP")])
+def test_module_engine_graph_replay_matches_eager_batched_passes(ds, model, monkeypatch):
+    """ModuleEngine on the GPU: passes replayed as hipGraphs (captured at their second occurrence; the optimizer object
+    kept and reset in place per round) against the same client-batched passes launched eagerly."""
+    import torch
+    from p2pfl_amd.node_start import build_dataset_and_model, build_model
+    from p2pfl_amd.runtime.module_engine import ModuleEngine, ModuleSpec
+    monkeypatch.setenv("P2PFL_MODULE_VMAP_STRICT", "1")
+    probe = build_dataset_and_model(ds, model, 0, 20)[0]
+    spec = ModuleSpec(f"{ds}-{model}", lambda: build_model(ds, model), probe.num_classes, tuple(probe.input_shape))
+    K, n = 4, 96
+    t = probe.tensors()
+    reps = -(-n // t[0].shape[0])
+    data = [torch.stack([torch.cat([t[j]] * reps)[:n if j < 2 else 32] for _ in range(K)]) for j in range(6)]
+    engines = {}
+    for graph in ("0", "1"):
+        monkeypatch.setenv("P2PFL_MODULE_GRAPH", graph)
+        eng = ModuleEngine(spec, K, "cuda", seed=1, batched=True, batch_size=32)
+        for m in eng.modules:
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = 0.0
+        eng.set_data(*data)
+        eng.init_params(identical=False)
+        engines[graph] = eng
+    assert engines["1"].use_graph and not engines["0"].use_graph
+    for rnd in range(2):
+        res = {}
+        for graph, eng in engines.items():
+            ev = eng.evaluate()
+            out = eng.fit(2, active=torch.tensor([True, True, False, True]))
+            res[graph] = (ev["loss"], out["Train"]["loss"], out["Train"]["count"])
+        assert torch.allclose(res["0"][0], res["1"][0], atol=2e-3, rtol=2e-3), rnd
+        assert torch.allclose(res["0"][1], res["1"][1], atol=2e-3, rtol=2e-3), rnd
+        assert torch.equal(res["0"][2], res["1"][2])
+    g = engines["1"]
+    assert g.use_graph and len(g._graphs) >= 3          # test pass, training epoch, validation pass
+    assert torch.equal(g.params[2], engines["0"].params[2])          # the idle node kept its (identical) model
+    g.set_data(*data)
+    assert not g._graphs                                 # new data: the captured passes are dropped
+    g.evaluate(); g.fit(1)

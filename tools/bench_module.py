@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from p2pfl_amd.node_start import build_dataset_and_model, build_model  # noqa: E402
 from p2pfl_amd.runtime.module_engine import ModuleEngine, ModuleSpec  # noqa: E402
 
-CASES = [("SYSCALL", "MLP", 50, 320), ("WADI", "MLP", 50, 320), ("CIFAR10", "simplemobilenet", 10, 128), ("CIFAR10", "ResNet9", 10, 128),
+CASES = [("SYSCALL", "MLP", 50, 320), ("SYSCALL", "SVM", 50, 320), ("SYSCALL", "Autoencoder", 50, 320), ("WADI", "MLP", 50, 320), ("CIFAR10", "simplemobilenet", 10, 128), ("CIFAR10", "ResNet9", 10, 128),
          ("CIFAR10", "ResNet18", 10, 64)]
 dev = "cuda"
 os.environ["P2PFL_MODULE_VMAP_STRICT"] = "1"
@@ -24,22 +24,26 @@ for ds, model, K, n in CASES:
     reps = -(-n // t[0].shape[0])
     data = [torch.stack([torch.cat([t[j]] * reps)[:n if j < 2 else 32] for _ in range(K)]) for j in range(6)]
     times = {}
-    for batched in (False, True):
+    for mode in ("loop", "vmap", "vmap+graph"):
+        os.environ["P2PFL_MODULE_GRAPH"] = "1" if mode == "vmap+graph" else "0"
         try:
-            eng = ModuleEngine(spec, K, dev, seed=1, batched=batched, batch_size=32)
+            eng = ModuleEngine(spec, K, dev, seed=1, batched=mode != "loop", batch_size=32)
             eng.set_data(*data)
             eng.init_params()
-            eng.evaluate(); eng.fit(1)                       # warm-up (MIOpen kernel search, allocator)
+            for _ in range(3):                               # warm-up: MIOpen kernel search, allocator, graph capture
+                eng.evaluate(); eng.fit(1)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            eng.evaluate(); eng.fit(1)
+            eng.evaluate(); out = eng.fit(1)
+            float(out["Train"]["loss"].mean())
             torch.cuda.synchronize()
-            times[batched] = time.perf_counter() - t0
-            assert eng.batched == batched
+            times[mode] = time.perf_counter() - t0
+            assert eng.batched == (mode != "loop") and (mode != "vmap+graph" or eng.use_graph == (spec.augment is None))
         except Exception as exc:  # noqa: BLE001
-            times[batched] = float("nan")
-            print(f"  {ds}-{model} batched={batched} failed: {type(exc).__name__}: {str(exc)[:200]}")
+            times[mode] = float("nan")
+            print(f"  {ds}-{model} {mode} failed: {type(exc).__name__}: {str(exc)[:200]}")
         del eng
         torch.cuda.empty_cache()
-    print(f"{ds}-{model:16s} K={K:3d} n={n:4d}: per-node loop {times[False]*1e3:9.1f} ms   client-batched {times[True]*1e3:9.1f} ms   "
-          f"x{times[False] / times[True]:.1f}", flush=True)
+    print(f"{ds}-{model:16s} K={K:3d} n={n:4d}: per-node loop {times['loop']*1e3:8.1f} ms   client-batched {times['vmap']*1e3:8.1f} ms "
+          f"(x{times['loop'] / times['vmap']:.1f})   + hipGraph replay {times['vmap+graph']*1e3:8.1f} ms (x{times['loop'] / times['vmap+graph']:.1f})",
+          flush=True)

@@ -55,15 +55,20 @@ class CIFAR10DataModule(FederatedDataModule):
 
     @staticmethod
     def augment(x: torch.Tensor, generator=None) -> torch.Tensor:
-        """RandomCrop(32, padding=4) + RandomHorizontalFlip on a [B,3,32,32] batch."""
-        b = x.shape[0]
+        """RandomCrop(32, padding=4) + RandomHorizontalFlip on a [B,3,32,32] batch - one gather on the batch's device
+        (offsets and flips drawn there too, unless a host ``generator`` is given), no per-sample loop, no host
+        round trip."""
+        b, dev = x.shape[0], x.device
+        draw = dev if generator is None else generator.device
         xp = F.pad(x, (4, 4, 4, 4))
-        ox = torch.randint(0, 9, (b,), generator=generator)
-        oy = torch.randint(0, 9, (b,), generator=generator)
-        out = torch.stack([xp[i, :, oy[i]:oy[i] + 32, ox[i]:ox[i] + 32] for i in range(b)])
-        flip = torch.rand(b, generator=generator) < 0.5
-        out[flip] = out[flip].flip(-1)
-        return out
+        ox = torch.randint(0, 9, (b,), generator=generator, device=draw).to(dev)
+        oy = torch.randint(0, 9, (b,), generator=generator, device=draw).to(dev)
+        flip = (torch.rand(b, generator=generator, device=draw) < 0.5).to(dev)
+        ar = torch.arange(32, device=dev)
+        rows = oy.view(b, 1) + ar.view(1, 32)                                            # [b, 32]
+        cols = ox.view(b, 1) + torch.where(flip.view(b, 1), 31 - ar.view(1, 32), ar.view(1, 32))
+        bi = torch.arange(b, device=dev).view(b, 1, 1)
+        return xp[bi, :, rows.view(b, 32, 1), cols.view(b, 1, 32)].permute(0, 3, 1, 2).contiguous()
 
     def train_dataloader(self):
         return self._loader(self.train_x, self.train_y, True, drop_last=True)

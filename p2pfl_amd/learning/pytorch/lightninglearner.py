@@ -197,7 +197,7 @@ class LightningLearner(NodeLearner):
                 break
             xb, yb = xb.to(dev), yb.to(dev)
             if hasattr(self.data, "augment") and train:
-                xb = self.data.augment(xb.cpu()).to(dev)
+                xb = self.data.augment(xb)                  # on the batch's device (no host round trip)
             if train:
                 loss, pred = model.training_loss(xb, yb)
                 self._optimizer.zero_grad(set_to_none=True)

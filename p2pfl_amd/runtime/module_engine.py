@@ -140,8 +140,9 @@ class ModuleEngine(ShardEngine):
         # hipGraph replay of a whole batched pass (an epoch of steps incl. backward and optimizer, or an evaluation
         # pass): small families are launch-bound even client-batched (50 SYSCALL MLPs: ~50 kernels of microseconds per
         # step). A pass runs eagerly the first time (lazy initialisation, MIOpen search), is captured at its second
-        # occurrence and replayed from then on. Not with a host-side augmentation hook (its random draws would be
-        # baked into the graph). P2PFL_MODULE_GRAPH=0 keeps the passes eager.
+        # occurrence and replayed from then on. Not with an augmentation hook (see below). P2PFL_MODULE_GRAPH=0 keeps the passes eager.
+        # (Measured: capturing a training pass that contains the CIFAR-10 crop / flip gather ends in a segmentation
+        # fault inside hipStreamEndCapture on ROCm 7.2 - passes with an augmentation hook stay eager.)
         self.use_graph = (self.device.type == "cuda" and spec.augment is None
                           and os.environ.get("P2PFL_MODULE_GRAPH", "1") != "0")
         self._graphs: Dict[tuple, object] = {}

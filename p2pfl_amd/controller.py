@@ -327,7 +327,10 @@ class Controller:
             if not homogeneous:
                 raise ValueError("--engine batched needs the same dataset / model on every node")
             return True
-        return homogeneous and pair in BATCHED_PAIRS      # auto: the client-batched HIP kernels
+        # auto: every homogeneous scenario runs client-batched in one process per GPU (BATCHED_PAIRS on the hand-written
+        # kernels, the other families as torch.func.vmap steps / hipGraph replays: 20-120 x the per-node loop for the
+        # small models); mixed scenarios need one process per node
+        return homogeneous
 
     def create_topology(self, matrix=None):
         import numpy as np

@@ -126,6 +126,57 @@ static void run_il(const char* name, float* p, float* mv, long cs, int K, int M,
     fflush(stdout);
 }
 
+// loads and stores grouped BY ARRAY (U rows of p, then U rows of m, then U rows of v) instead of interleaved per row
+template <int COLS, int U>
+__global__ __launch_bounds__(256) void strip_update_grouped(float* p, float* m, float* v, long cs, int M, int N, int rows_per_block) {
+    constexpr int TPR = COLS / 4, R = 256 / TPR;
+    const int c = blockIdx.z;
+    const int col = blockIdx.x * COLS + (threadIdx.x % TPR) * 4;
+    const int row0 = blockIdx.y * rows_per_block + threadIdx.x / TPR;
+    const size_t base = (size_t)c * cs + (size_t)row0 * N + col;
+    const int steps = rows_per_block / R;
+    for (int s0 = 0; s0 < steps; s0 += U) {
+        f32x4 pv[U], mv[U], vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) pv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + base + (size_t)(s0 + u) * R * N));
+#pragma unroll
+        for (int u = 0; u < U; ++u) mv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m + base + (size_t)(s0 + u) * R * N));
+#pragma unroll
+        for (int u = 0; u < U; ++u) vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v + base + (size_t)(s0 + u) * R * N));
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float g = pv[u][j] * 1e-3f;
+                mv[u][j] = 0.9f * mv[u][j] + 0.1f * g;
+                vv[u][j] = 0.999f * vv[u][j] + 0.001f * g * g;
+                pv[u][j] -= 1e-3f * (mv[u][j] / (sqrtf(vv[u][j]) + 1e-8f));
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_nontemporal_store(pv[u], reinterpret_cast<f32x4*>(p + base + (size_t)(s0 + u) * R * N));
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_nontemporal_store(mv[u], reinterpret_cast<f32x4*>(m + base + (size_t)(s0 + u) * R * N));
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_nontemporal_store(vv[u], reinterpret_cast<f32x4*>(v + base + (size_t)(s0 + u) * R * N));
+    }
+}
+template <int COLS, int U>
+static void run_grouped(const char* name, float* p, float* m, float* v, long cs, int K, int M, int N, int rpb) {
+    dim3 grid(N / COLS, M / rpb, K);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((strip_update_grouped<COLS, U>), grid, dim3(256), 0, 0, p, m, v, cs, M, N, rpb);
+    hipEventRecord(e0, 0);
+    const int reps = 5;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((strip_update_grouped<COLS, U>), grid, dim3(256), 0, 0, p, m, v, cs, M, N, rpb);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    const double gb = 6.0 * K * (double)M * N * 4 / 1e9;
+    printf("%-34s cols %4d U %d rows/block %4d blocks %6d: %.3f ms  %.2f TB/s\n", name, COLS, U, rpb, grid.x * grid.y * grid.z, ms, gb / ms);
+    fflush(stdout);
+}
+
 int main() {
     const int K = 100, M = 2048, N = 3072;
     const long cs = (long)M * N;
@@ -148,6 +199,11 @@ int main() {
     run<1024, 2, true>("strip 4 KB, 64-row blocks", p, m, v, cs, K, M, N, 64);
     run<1024, 4, true>("strip 4 KB, 16-row blocks", p, m, v, cs, K, M, N, 16);
     run<1024, 4, false>("strip 4 KB, 16-row blocks", p, m, v, cs, K, M, N, 16);
+    run_grouped<128, 8>("grouped by array, 512 B", p, m, v, cs, K, M, N, 2048);
+    run_grouped<128, 8>("grouped by array, 512 B 128-row", p, m, v, cs, K, M, N, 128);
+    run_grouped<1024, 8>("grouped by array, 4 KB 64-row", p, m, v, cs, K, M, N, 64);
+    run_grouped<1024, 16>("grouped by array, 4 KB 64-row", p, m, v, cs, K, M, N, 64);
+    run_grouped<128, 16>("grouped by array, 512 B", p, m, v, cs, K, M, N, 2048);
     // interleaved layouts: p is the first third / p + cs*K.. (the three allocations are used as one pool here)
     float* pool; hipMalloc(&pool, 3 * K * cs * 4); hipMemset(pool, 0, 3 * K * cs * 4);
     run_il<128, 4, 1>("w + [m v] interleaved, 512 B", pool, pool + K * cs, cs, K, M, N, 2048);

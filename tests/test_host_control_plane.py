@@ -197,10 +197,12 @@ def test_batched_launcher_serves_the_control_plane(tmp_path, monkeypatch):
                                      controller="", overrides=over)
     for i in range(4):
         path = os.path.join(cdir, f"participant_{i}.json")
-        p = json.load(open(path))
+        with open(path) as fh:
+            p = json.load(fh)
         p["network_args"]["neighbors"] = " ".join(f"127.0.0.1:{45000 + j}" for j in ((i - 1) % 4, (i + 1) % 4))
         p["scenario_args"]["name"] = "scen"
-        json.dump(p, open(path, "w"))
+        with open(path, "w") as fh:
+            json.dump(p, fh)
     out = {}
     t = threading.Thread(target=lambda: out.update(run_scenario(cdir, device="cpu", gateways=[f"0:{port}"],
                                                                 wait_start=60.0)), daemon=True)
@@ -216,7 +218,7 @@ def test_batched_launcher_serves_the_control_plane(tmp_path, monkeypatch):
     finally:
         ext.stop()
     assert out["rounds"] == 2 and out["nodes"] == 4
-    log0 = open(tmp_path / "logs" / "scen" / "participant_0.log").read()
+    log0 = (tmp_path / "logs" / "scen" / "participant_0.log").read_text()
     assert "TCP gateway of virtual node 0" in log0 and "round 1 role" in log0
     assert os.path.exists(tmp_path / "logs" / "scen" / "metrics" / "participant_2" / "metrics.csv")
 

@@ -70,3 +70,16 @@ def test_fused_update_occupancy():
             assert occ == 2 and vg <= 192, (fresh, vg, occ)
         else:
             assert occ >= 2, (fresh, vg, occ)
+
+
+def test_in_process_federation_tests_pass_in_python_dev_mode():
+    """SURVEY 4.2 tier 6: the in-process federation / host-component tests under ``python -X dev -X faulthandler``
+    with resource warnings promoted to errors (unclosed sockets / files, un-awaited threads' exceptions)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-X", "dev", "-X", "faulthandler", "-W", "error::ResourceWarning", "-m", "pytest",
+                        "tests/test_federation_cpu.py", "tests/test_host_components.py", "-x", "-q", "-p", "no:cacheprovider"],
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "ResourceWarning" not in r.stdout and "Exception ignored" not in r.stdout

@@ -251,6 +251,13 @@ class Controller:
         participant_files = sorted(glob.glob(os.path.join(self.config_dir, "participant_*.json")),
                                    key=lambda p: int(os.path.basename(p).split("_")[1].split(".")[0]))
         if not participant_files:
+            # a scenario described by ONE file (config/scenario.py) is expanded into the per-participant documents
+            from .config.scenario import SCENARIO_FILE, emit_participants
+            for cand in (self.config_dir, os.path.dirname(os.path.normpath(self.config_dir))):
+                if os.path.exists(os.path.join(cand, SCENARIO_FILE)):
+                    participant_files = emit_participants(os.path.join(cand, SCENARIO_FILE), self.config_dir)
+                    break
+        if not participant_files:
             raise ValueError("No participant files found in config folder")
         self.config.set_participants_config(participant_files)
         self.n_nodes = len(participant_files)
@@ -289,6 +296,9 @@ class Controller:
                 json.dump(pc, f, sort_keys=False, indent=2)
         if not is_start_node:
             raise ValueError("No start node found")
+        # the same scenario as ONE file (defaults + per-node deltas) beside the per-participant documents
+        from .config.scenario import write_scenario
+        write_scenario(self.config_dir)
         self.config.set_participants_config(participant_files)
         self.topologymanager.update_nodes(self.config.participants)
         try:

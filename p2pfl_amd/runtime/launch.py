@@ -38,10 +38,16 @@ _SPEC_OF = {("MNIST", "MLP"): "mnist-mlp", ("MNIST", "CNN"): "mnist-cnn", ("FEMN
 
 
 def load_participants(config_dir: str) -> List[dict]:
+    """Participant documents of a scenario: the ``participant_<i>.json`` files, or - when there are none - the single
+    ``scenario.json`` (config/scenario.py: one file for all N nodes, so 1000 co-resident clients need not be 1000
+    files)."""
     files = sorted(glob.glob(os.path.join(config_dir, "participant_*.json")),
                    key=lambda p: int(os.path.basename(p).split("_")[1].split(".")[0]))
     if not files:
-        raise ValueError(f"No participant files found in {config_dir}")
+        from ..config.scenario import SCENARIO_FILE, read_scenario
+        if os.path.exists(os.path.join(config_dir, SCENARIO_FILE)):
+            return [_deep_update(default_participant(), p) for p in read_scenario(config_dir)]
+        raise ValueError(f"No participant files (or {SCENARIO_FILE}) found in {config_dir}")
     out = []
     for f in files:
         with open(f) as fh:

@@ -235,7 +235,9 @@ def main() -> None:
         base = eager_baseline_samples_per_sec() if args.config is None and args.impl == "hip" else None
         out = {
             "metric": "aggregate client samples/sec (federated rounds, MNIST CNN, 100 nodes per GPU)"
-            if args.config is None else f"aggregate client samples/sec (federated rounds, {args.config})",
+            if args.config is None and spec.name == "mnist-cnn" and args.nodes_per_gpu == 100
+            else f"aggregate client samples/sec (federated rounds, {args.config or spec.name}, "
+                 f"{args.nodes_per_gpu} nodes per GPU)",
             "value": sps,
             "unit": "samples/s",
             "n_gpus": world,

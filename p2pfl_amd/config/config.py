@@ -133,8 +133,15 @@ class Config:
     # kept under the reference's mangled-looking public alias too
     _Config__adjust_block_size = _adjust_block_size
 
+    def view(self):
+        """Typed, validated snapshot of ``participant`` (config/schema.py); the dict stays the live, mutable state."""
+        from .schema import ParticipantView
+        return ParticipantView.from_dict(self.participant)
+
     @staticmethod
     def validate(p: Dict[str, Any]) -> None:
+        from .schema import ParticipantView
+        ParticipantView.from_dict(p)          # types, ranges, known federations / roles / accelerators
         for key in TUNABLES:
             if key not in p:
                 raise ValueError(f"participant config misses {key}")

@@ -297,7 +297,9 @@ class Controller:
         if not is_start_node:
             raise ValueError("No start node found")
         # the same scenario as ONE file (defaults + per-node deltas) beside the per-participant documents
-        from .config.scenario import write_scenario
+        from .config.scenario import read_participant_files, write_scenario
+        from .config.schema import validate_scenario
+        validate_scenario(read_participant_files(self.config_dir))      # typed checks across the whole scenario
         write_scenario(self.config_dir)
         self.config.set_participants_config(participant_files)
         self.topologymanager.update_nodes(self.config.participants)

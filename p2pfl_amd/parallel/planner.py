@@ -26,7 +26,7 @@ from __future__ import annotations
 
 import hashlib
 from dataclasses import dataclass, field
-from typing import Dict, List, Sequence
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
@@ -34,15 +34,108 @@ XGMI_LINK_BYTES_PER_S = 153e9      # per direction, per link (MI355X: 7 links pe
 XGMI_LINKS = 7
 
 
-def partition_nodes(n_nodes: int, world: int) -> List[range]:
-    """Contiguous, balanced blocks of node ids per rank."""
-    base, rem = divmod(n_nodes, world)
+def partition_nodes(n_nodes: int, world: int, sizes: Optional[Sequence[int]] = None) -> List[range]:
+    """Contiguous blocks of node ids per rank: balanced, or ``sizes[r]`` nodes on rank r (explicit placement: the
+    launcher orders the nodes by ``device_args.placement`` first, see :func:`placement_order`)."""
+    if sizes is not None:
+        sizes = [int(c) for c in sizes]
+        if len(sizes) != world or sum(sizes) != n_nodes or min(sizes) < 1:
+            raise ValueError(f"block sizes {sizes} do not place {n_nodes} nodes on {world} ranks (every rank hosts >= 1)")
+    else:
+        base, rem = divmod(n_nodes, world)
+        sizes = [base + (1 if r < rem else 0) for r in range(world)]
     out, start = [], 0
-    for r in range(world):
-        cnt = base + (1 if r < rem else 0)
+    for cnt in sizes:
         out.append(range(start, start + cnt))
         start += cnt
     return out
+
+
+def placement_order(placements: Sequence[Optional[int]], world: int):
+    """``device_args.placement`` of every participant (rank that hosts the node; ``None`` = anywhere) ->
+    ``(order, sizes)``: the node order that makes every rank's nodes one contiguous block, and the block sizes.
+    Unplaced nodes fill the emptiest ranks, in index order. ``(identity, None)`` when nobody names a placement."""
+    n = len(placements)
+    if all(p is None for p in placements):
+        return list(range(n)), None
+    buckets: List[List[int]] = [[] for _ in range(world)]
+    free = []
+    for i, p in enumerate(placements):
+        if p is None:
+            free.append(i)
+        elif not 0 <= int(p) < world:
+            raise ValueError(f"participant {i}: placement {p} outside the {world} ranks of this launch")
+        else:
+            buckets[int(p)].append(i)
+    for i in free:
+        min(buckets, key=len).append(i)
+    if any(not b for b in buckets):
+        raise ValueError("placement leaves a rank without nodes")
+    return [i for b in buckets for i in sorted(b)], [len(b) for b in buckets]
+
+
+def locality_placement(adj: np.ndarray, world: int, passes: int = 8) -> List[int]:
+    """A placement (rank per node) that keeps neighbours together: breadth-first order from a lowest-degree node
+    (Cuthill-McKee), cut into balanced blocks, then refined by pairwise swaps. Rows that cross a rank boundary are what the xGMI exchange has to move
+    (``plan_exchange``), so fewer cut links = fewer staged rows; a ring stays at 2 cut links per boundary, a random
+    graph loses a third to a half of its cut."""
+    a = np.asarray(adj) != 0
+    a = a | a.T
+    n = a.shape[0]
+    deg = a.sum(1)
+    seen = np.zeros(n, dtype=bool)
+    order: List[int] = []
+    while len(order) < n:
+        rest = np.flatnonzero(~seen)
+        root = int(rest[np.argmin(deg[rest])])
+        seen[root] = True
+        queue = [root]
+        while queue:
+            u = queue.pop(0)
+            order.append(u)
+            nb = [int(v) for v in np.flatnonzero(a[u] & ~seen)]
+            nb.sort(key=lambda v: (deg[v], v))
+            for v in nb:
+                seen[v] = True
+            queue.extend(nb)
+    place = np.zeros(n, dtype=np.int64)
+    for r, blk in enumerate(partition_nodes(n, world)):
+        place[[order[k] for k in blk]] = r
+    # refinement: swap a node with the node of its favourite rank that gains most from moving the other way
+    # (Kernighan-Lin moves; block sizes never change), until a pass finds nothing
+    ai = a.astype(np.int64)
+    cnt = ai @ np.eye(world, dtype=np.int64)[place]              # [n, world]: neighbours of u on rank r
+    for _ in range(passes):
+        improved = False
+        for u in range(n):
+            ra = int(place[u])
+            rb = int(np.argmax(cnt[u]))
+            if rb == ra or cnt[u, rb] <= cnt[u, ra]:
+                continue
+            cand = np.flatnonzero(place == rb)
+            gain = (cnt[u, rb] - cnt[u, ra]) + (cnt[cand, ra] - cnt[cand, rb]) - 2 * ai[u, cand]
+            k = int(np.argmax(gain))
+            if gain[k] <= 0:
+                continue
+            v = int(cand[k])
+            for w, src, dst in ((u, ra, rb), (v, rb, ra)):
+                nb = np.flatnonzero(a[w])
+                cnt[nb, src] -= 1
+                cnt[nb, dst] += 1
+                place[w] = dst
+            improved = True
+        if not improved:
+            break
+    return [int(r) for r in place]
+
+
+def cut_links(adj: np.ndarray, place: Sequence[int]) -> int:
+    """Undirected links whose two ends sit on different ranks."""
+    a = np.asarray(adj) != 0
+    a = np.triu(a | a.T, 1)
+    pl = np.asarray(place)
+    i, j = np.nonzero(a)
+    return int((pl[i] != pl[j]).sum())
 
 
 def owner_of(n_nodes: int, world: int) -> np.ndarray:

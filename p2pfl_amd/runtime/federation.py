@@ -69,7 +69,8 @@ class BatchedFederation:
                  scenario: str = "scenario", persist_optimizer: bool = False, use_graph: bool = True,
                  overlap: bool = True, heartbeat_period: float = 4.0, node_timeout: float = 20.0,
                  instant_detection: bool = True, precision: Optional[str] = None,
-                 aggregation_timeout: float = 60.0, virtual_devices: int = 1):
+                 aggregation_timeout: float = 60.0, virtual_devices: int = 1,
+                 block_sizes: Optional[Sequence[int]] = None):
         self.spec = spec
         self.adj = np.asarray(topology, dtype=np.float32)
         self.N = self.adj.shape[0]
@@ -81,7 +82,7 @@ class BatchedFederation:
         self.encrypt = encrypt
         self.scenario = scenario
         self.device = torch.device(device)
-        self.blocks = partition_nodes(self.N, self.world)
+        self.blocks = partition_nodes(self.N, self.world, block_sizes)   # block_sizes: explicit placement (launch.py)
         self.owner = np.zeros(self.N, dtype=np.int64)
         for r, blk in enumerate(self.blocks):
             self.owner[list(blk)] = r

@@ -32,6 +32,7 @@ from ..learning.metrics import metrics_from_confusion
 from ..learning.pytorch.statisticslogger import CSVLogger
 from ..models.specs import get_spec
 from ..node_start import build_dataset_and_model, build_model
+from ..parallel.planner import locality_placement, placement_order
 from .federation import BatchedFederation
 
 _SPEC_OF = {("MNIST", "MLP"): "mnist-mlp", ("MNIST", "CNN"): "mnist-cnn", ("FEMNIST", "CNN"): "femnist-cnn"}
@@ -90,7 +91,7 @@ def _parse_gateway(text: str):
 
 def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, save_models: bool = False,
                  rounds: int = None, resume: str = None, virtual_devices: int = 1, control_plane: bool = False,
-                 gateways=(), wait_start: float = None) -> dict:
+                 gateways=(), wait_start: float = None, placement: str = None) -> dict:
     """Run the scenario of ``config_dir`` on this rank's GPU.
 
     ``control_plane`` (one rank): the co-resident nodes get the reference's protocol behaviour from a
@@ -115,8 +116,20 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
         pg = dist.group.WORLD
 
     parts = load_participants(config_dir)
-    p0 = parts[0]
     n = len(parts)
+    # placement: ``device_args.placement`` = the rank (GPU) that hosts a node; ``scenario_args.placement ==
+    # "locality"`` (or ``placement``) lets the planner keep neighbours on one GPU. Internally the nodes are ordered so
+    # that every rank's nodes are one block of slab rows; ``ext[k]`` is the participant index of internal node k and
+    # names everything that leaves the process (files, logs, fault schedules, gateways, events).
+    wanted = [p["device_args"].get("placement") for p in parts]
+    wanted = [None if w in (None, "", "auto") else int(w) for w in wanted]          # "auto" (the default): anywhere
+    mode = placement or parts[0]["scenario_args"].get("placement")
+    if mode == "locality" and world > 1 and all(w is None for w in wanted):
+        wanted = locality_placement(adjacency_from_participants(parts), world)
+    ext, block_sizes = placement_order(wanted, world)
+    pos = {e: k for k, e in enumerate(ext)}
+    parts = [parts[e] for e in ext]
+    p0 = parts[pos[0]]
     key = (p0["data_args"]["dataset"], p0["model_args"]["model"])
     root_dir = p0["data_args"].get("root_dir")
     if key in _SPEC_OF:
@@ -142,11 +155,12 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
                             aggregation_timeout=float(p0.get("AGGREGATION_TIMEOUT", 60)),
                             # the reference's failure semantics: a dead node is waited for (AGGREGATION_TIMEOUT, on
                             # the virtual clock) until the heartbeat table evicts it NODE_TIMEOUT later
-                            instant_detection=False, virtual_devices=virtual_devices)
+                            instant_detection=False, virtual_devices=virtual_devices, block_sizes=block_sizes)
     for f in load_faults(config_dir, parts):
-        fed.schedule_fault(int(f["round"]), f["action"], int(f["node"]), f.get("peer"), f.get("phase", "start"))
+        fed.schedule_fault(int(f["round"]), f["action"], pos[int(f["node"])],
+                           None if f.get("peer") is None else pos[int(f["peer"])], f.get("phase", "start"))
     # data shards of the local nodes (real files when present, synthetic otherwise)
-    shards = [build_dataset_and_model(key[0], key[1], i, n, root_dir)[0] for i in fed.local]
+    shards = [build_dataset_and_model(key[0], key[1], ext[i], n, root_dir)[0] for i in fed.local]
 
     # rows per split: the smallest shard of the WHOLE scenario (splits can differ by a row between nodes), agreed
     # across ranks so that every rank stacks the same shape
@@ -178,7 +192,7 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
         from ..learning.codec import load_checkpoint
         metas = []
         for k, i in enumerate(fed.local):
-            arrays, _, _, meta = load_checkpoint(os.path.join(resume, f"participant_{i}_final.ckpt"))
+            arrays, _, _, meta = load_checkpoint(os.path.join(resume, f"participant_{ext[i]}_final.ckpt"))
             fed.engine.set_arrays(k, arrays)
             metas.append(meta or {})
             first_round = max(first_round, int((meta or {}).get("round", 0)))
@@ -194,8 +208,8 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
     fed.prepare()       # captured graphs / exchange plan before round 0 (models and counters stay as they are)
     log_root = os.path.join(p0["tracking_args"].get("log_dir") or "logs", scenario)
     os.makedirs(log_root, exist_ok=True)
-    loggers = {i: CSVLogger(log_root, name="metrics", version=f"participant_{i}") for i in fed.local}
-    node_logs = {i: open(os.path.join(log_root, f"participant_{i}.log"), "a") for i in fed.local}
+    loggers = {i: CSVLogger(log_root, name="metrics", version=f"participant_{ext[i]}") for i in fed.local}
+    node_logs = {i: open(os.path.join(log_root, f"participant_{ext[i]}.log"), "a") for i in fed.local}
 
     def node_log(i, msg):
         node_logs[i].write(f"[{time.strftime('%Y-%m-%d %H:%M:%S')}] {msg}\n")
@@ -256,8 +270,9 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
         host.start()
         for g in gateways:
             vidx, gh, gp = _parse_gateway(g)
+            vidx = pos[vidx]
             gw = host.gateway(vidx, gh or parts[vidx]["network_args"]["ip"], gp)
-            node_log(vidx, f"TCP gateway of virtual node {vidx} listening on {gw.get_name()}")
+            node_log(vidx, f"TCP gateway of virtual node {ext[vidx]} listening on {gw.get_name()}")
         if wait_start is not None:
             if not host.wait_started(wait_start):
                 logging.warning("no START_LEARNING within %.0f s: starting locally", wait_start)
@@ -275,7 +290,7 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
     elapsed = time.time() - t0
     if save_models:
         for k, i in enumerate(fed.local):
-            save_checkpoint(os.path.join(log_root, f"participant_{i}_final.ckpt"),
+            save_checkpoint(os.path.join(log_root, f"participant_{ext[i]}_final.ckpt"),
                             fed.engine.get_arrays(k),
                             [f"{parts[i]['network_args']['ip']}:{parts[i]['network_args']['port']}"],
                             int(fed.weights[i]), meta={"round": first_round + rounds, "role": fed.roles[i]})
@@ -287,7 +302,9 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
                "rounds": rounds, "seconds": elapsed, "rounds_per_sec": rounds / max(elapsed, 1e-9),
                "samples_per_sec": total_samples / elapsed, "final_test_accuracy": float(final["accuracy"].mean()),
                "final_test_loss": float(final["loss"].mean()), "first_round": first_round,
-               "membership_events": [[round(t, 3), what, node] for t, what, node in fed.membership.events]}
+               "membership_events": [[round(t, 3), what, ext[int(node)]]
+                                     for t, what, node in fed.membership.events],
+               "placement": None if block_sizes is None else {"block_sizes": block_sizes, "order": ext}}
     if rank == 0:
         with open(os.path.join(log_root, "summary.json"), "w") as f:
             json.dump(summary, f, indent=2)
@@ -313,13 +330,16 @@ def main(argv=None):
                          "(implies --control-plane; repeatable)")
     ap.add_argument("--wait-start", type=float, default=None, metavar="SECONDS",
                     help="with a gateway: wait this long for START_LEARNING from an external node instead of starting")
+    ap.add_argument("--placement", default=None, choices=["locality"],
+                    help="multi-GPU: let the planner place neighbours on the same GPU (fewer rows over xGMI); explicit "
+                         "placements are read from device_args.placement")
     ap.add_argument("--virtual-devices", type=int, default=1,
                     help="one-GPU runs: split the nodes into this many virtual devices whose exchange takes the "
                          "inter-GPU path (staging + per-link AES with --encrypt)")
     a = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO)
     print(json.dumps(run_scenario(a.config_dir, a.device, a.encrypt, a.save_models, a.rounds, a.resume,
-                                  a.virtual_devices, a.control_plane, a.gateway, a.wait_start)), flush=True)
+                                  a.virtual_devices, a.control_plane, a.gateway, a.wait_start, a.placement)), flush=True)
 
 
 if __name__ == "__main__":

@@ -30,9 +30,9 @@ def topo(kind, n, seed=0):
     return tm.topology
 
 
-def make_fed(kind, n, federation="DFL", rank=0, world=1, pg=None, encrypt=False, n_train=32):
+def make_fed(kind, n, federation="DFL", rank=0, world=1, pg=None, encrypt=False, n_train=32, block_sizes=None):
     fed = BatchedFederation(SPEC, topo(kind, n), federation=federation, device="cpu", engine="eager", epochs=1, seed=5,
-                            rank=rank, world_size=world, process_group=pg, encrypt=encrypt)
+                            rank=rank, world_size=world, process_group=pg, encrypt=encrypt, block_sizes=block_sizes)
     data = synthetic_shards(fed.n_local, n_train, 8, 16, 10, seed=1, first_client=fed.local.start)
     fed.init_params()
     fed.set_local_data(*data)
@@ -181,11 +181,11 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, kind, encrypt, out):
+def _worker(rank, world, port, kind, encrypt, out, block_sizes=None):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
-    fed = make_fed(kind, 6, rank=rank, world=world, pg=dist.group.WORLD, encrypt=encrypt)
+    fed = make_fed(kind, 6, rank=rank, world=world, pg=dist.group.WORLD, encrypt=encrypt, block_sizes=block_sizes)
     perturb(fed)
     fed.run_round(evaluate=False)
     fed.run_round(evaluate=False)
@@ -204,6 +204,19 @@ def test_two_rank_exchange_matches_single_rank(kind, encrypt):
     mp.spawn(_worker, args=(2, _free_port(), kind, encrypt, out), nprocs=2, join=True)
     got = torch.cat([out[0], out[1]], dim=0)
     assert torch.allclose(got, ref.engine.params[:, :8], atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["random", "fully"])
+def test_uneven_placement_matches_single_rank(kind):
+    """explicit placement (device_args.placement -> block sizes): 5 nodes on rank 0, 1 on rank 1"""
+    ref = make_fed(kind, 6)
+    perturb(ref)
+    ref.run_round(evaluate=False)
+    ref.run_round(evaluate=False)
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(2, _free_port(), kind, False, out, [5, 1]), nprocs=2, join=True)
+    assert out[0].shape[0] == 5 and out[1].shape[0] == 1
+    assert torch.allclose(torch.cat([out[0], out[1]], dim=0), ref.engine.params[:, :8], atol=1e-6)
 
 
 # ------------------------------------------------------------------ churn with the reference's failure semantics

@@ -4,7 +4,8 @@ of its contributors, and the fully connected / star cases collapse to one all-re
 import numpy as np
 import pytest
 
-from p2pfl_amd.parallel.planner import (estimate_exchange_seconds, owner_of, partition_nodes, plan_exchange)
+from p2pfl_amd.parallel.planner import (cut_links, estimate_exchange_seconds, locality_placement, owner_of,
+                                        partition_nodes, placement_order, plan_exchange)
 from p2pfl_amd.utils.topologymanager import TopologyManager
 
 
@@ -99,3 +100,56 @@ def test_inplace_reduce_is_a_gpu_only_path():
     out = slab.clone()
     fedavg_reference(slab, None, out, plan)
     assert torch.allclose(out[2], 0.25 * slab[0] + 0.75 * slab[1]) and torch.equal(out[:2], slab[:2])
+
+
+def test_explicit_placement_orders_nodes_into_blocks():
+    assert [list(b) for b in partition_nodes(6, 2, [5, 1])] == [[0, 1, 2, 3, 4], [5]]
+    for bad in ([3, 2], [6, 0], [2, 2, 2]):
+        with pytest.raises(ValueError):
+            partition_nodes(6, 2, bad)
+    assert placement_order([None] * 4, 2) == ([0, 1, 2, 3], None)
+    order, sizes = placement_order([1, 0, 1, 0, 0], 2)
+    assert order == [1, 3, 4, 0, 2] and sizes == [3, 2]
+    order, sizes = placement_order([1, None, None, 1, None], 2)        # unplaced nodes fill the emptiest rank
+    assert sizes == [3, 2] and sorted(order) == [0, 1, 2, 3, 4] and order[:3] == [1, 2, 4]
+    with pytest.raises(ValueError):
+        placement_order([0, 2], 2)
+    with pytest.raises(ValueError):
+        placement_order([0, 0], 2)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_locality_placement_cuts_fewer_links_and_stays_balanced(world):
+    n = 25 * world
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(n)                      # a ring + chords whose node numbering says nothing about adjacency
+    adj = np.zeros((n, n), dtype=np.float32)
+    for k in range(n):
+        a, b = perm[k], perm[(k + 1) % n]
+        adj[a, b] = adj[b, a] = 1
+    for a, b in rng.integers(0, n, size=(n // 4, 2)):
+        if a != b:
+            adj[a, b] = adj[b, a] = 1
+    naive = owner_of(n, world)
+    place = locality_placement(adj, world)
+    counts = np.bincount(place, minlength=world)
+    assert counts.max() - counts.min() <= 1
+    assert cut_links(adj, place) < 0.6 * cut_links(adj, naive)
+    # a plain ring numbered in order is already optimal and stays so
+    ring = np.zeros((n, n), dtype=np.float32)
+    for k in range(n):
+        ring[k, (k + 1) % n] = ring[(k + 1) % n, k] = 1
+    assert cut_links(ring, locality_placement(ring, world)) <= max(cut_links(ring, owner_of(n, world)), 2 * world)
+    # fewer cut links = fewer rows over the fabric
+    order, sizes = placement_order(place, world)
+    inv = np.argsort(order)
+    ts = {int(inv[i]): sorted(int(inv[j]) for j in list(np.nonzero(adj[i])[0]) + [i]) for i in range(n)}
+    blocks = partition_nodes(n, world, sizes)
+    own = np.zeros(n, dtype=np.int64)
+    for r, b in enumerate(blocks):
+        own[list(b)] = r
+    rows_placed = sum(plan_exchange(ts, {}, own, [1.0] * n, r, world, blocks[r]).rows_sent() for r in range(world))
+    ts0 = {i: sorted([int(j) for j in np.nonzero(adj[i])[0]] + [i]) for i in range(n)}
+    b0 = partition_nodes(n, world)
+    rows_naive = sum(plan_exchange(ts0, {}, naive, [1.0] * n, r, world, b0[r]).rows_sent() for r in range(world))
+    assert rows_placed < rows_naive

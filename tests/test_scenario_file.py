@@ -96,5 +96,112 @@ def test_controller_writes_and_ingests_scenario_json(tmp_path):
     for i in range(5):
         with open(os.path.join(cdir, f"participant_{i}.json")) as f:
             p = json.load(f)
-        assert p["network_args"]["neighbors"] == per_file[i]["network_args"]["neighbors"]
-        assert p["device_args"]["role"] == per_file[i]["device_args"]["role"]
+        # (the controller draws the topology again, so only the ring itself is the same)
+        assert {f"127.0.0.1:{per_file[j]['network_args']['port']}" for j in ((i - 1) % 5, (i + 1) % 5)} \
+            <= set(p["network_args"]["neighbors"].split())
+        assert p["network_args"]["port"] == per_file[i]["network_args"]["port"]
+        assert p["device_args"]["idx"] == i and p["device_args"]["role"] == per_file[i]["device_args"]["role"]
+
+
+def test_two_rank_launch_honours_device_args_placement(tmp_path):
+    """``device_args.placement`` = the rank that hosts a node: the launcher orders the nodes into per-rank blocks
+    internally, everything that leaves the process (logs, metrics, checkpoints, fault schedule, events) keeps the
+    participant's own index."""
+    import socket
+    import subprocess
+    import sys
+    cdir = os.path.join(str(tmp_path), "config", "scen")
+    Controller.generate_participants(cdir, 5, "DFL", "MNIST", "MLP", rounds=2, epochs=1, accelerator="cpu",
+                                     controller="", overrides={"tracking_args": {"log_dir": str(tmp_path / "logs")}})
+    placement = [1, 0, 1, 0, 0]
+    for i in range(5):
+        path = os.path.join(cdir, f"participant_{i}.json")
+        with open(path) as f:
+            p = json.load(f)
+        p["network_args"]["neighbors"] = " ".join(f"127.0.0.1:{45000 + j}" for j in ((i - 1) % 5, (i + 1) % 5))
+        p["scenario_args"]["name"] = "scen"
+        p["device_args"]["placement"] = placement[i]
+        with open(path, "w") as f:
+            json.dump(p, f)
+    with open(os.path.join(cdir, "faults.json"), "w") as f:
+        json.dump([{"round": 1, "action": "kill", "node": 2}], f)        # participant 2 lives on rank 1
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "p2pfl_amd.runtime.launch",
+                        cdir, "--device", "cpu", "--save-models"], cwd=root, capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, OMP_NUM_THREADS="2"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    logs = tmp_path / "logs" / "scen"
+    with open(logs / "summary.json") as f:
+        s = json.load(f)
+    assert s["nodes"] == 5 and s["world"] == 2 and s["local_nodes"] == 3 and s["rounds"] == 2
+    assert s["placement"] == {"block_sizes": [3, 2], "order": [1, 3, 4, 0, 2]}
+    assert ["kill", 2] in [e[1:] for e in s["membership_events"]]
+    for i in range(5):
+        assert (logs / f"participant_{i}.log").exists() and (logs / f"participant_{i}_final.ckpt").exists()
+        assert (logs / "metrics" / f"participant_{i}" / "metrics.csv").exists()
+    with open(logs / "participant_2.log") as f:
+        log2 = f.read()
+    assert "round 0 role aggregator alive True" in log2 and "round 1 role aggregator alive False" in log2
+    with open(logs / "participant_0.log") as f:
+        assert "round 1 role aggregator alive True" in f.read()
+
+
+# ------------------------------------------------------------------ typed view (config/schema.py)
+def test_typed_view_coerces_defaults_and_round_trips():
+    from p2pfl_amd.config.config import Config
+    from p2pfl_amd.config.schema import ParticipantView
+    d = default_participant()
+    d["device_args"].update(idx="3", start="true", placement="1", gpu="")
+    d["network_args"].update(port="45003", neighbors="127.0.0.1:45002 127.0.0.1:45004")
+    d["geo_args"].update(latitude="38.02", longitude=-1.17)
+    d["adversarial_args"] = {"attacks": "No Attack"}
+    d["data_args"]["root_dir"] = "/data"
+    v = ParticipantView.from_dict(d)
+    assert v.device.idx == 3 and v.device.start is True and v.device.placement == 1 and v.device.gpu is None
+    assert v.network.port == 45003 and v.network.neighbor_list() == ["127.0.0.1:45002", "127.0.0.1:45004"]
+    assert v.tunables.BLOCK_SIZE == 2048 and v.dataset == "MNIST" and v.epochs == 3
+    back = v.to_dict()
+    assert back["adversarial_args"] == {"attacks": "No Attack"} and back["data_args"] == {"dataset": "MNIST", "root_dir": "/data"}
+    assert back["network_args"]["delay-distro"] == 0 and back["device_args"]["idx"] == 3
+    assert ParticipantView.from_dict(back) == v
+    assert Config(participant=d).view().device.idx == 3
+
+
+@pytest.mark.parametrize("section,key,value", [
+    ("scenario_args", "federation", "XFL"), ("device_args", "role", "boss"), ("device_args", "accelerator", "tpu"),
+    ("network_args", "port", 70000), ("network_args", "port", "http"), ("network_args", "neighbors", "127.0.0.1"),
+    ("geo_args", "latitude", 123.0), ("training_args", "epochs", 0), ("aggregator_args", "algorithm", "Krum"),
+    (None, "NODE_TIMEOUT", 2), (None, "GOSSIP_MODELS_FREC", 0), ("device_args", "placement", -1)])
+def test_typed_view_rejects_what_the_runtime_cannot_act_on(section, key, value):
+    from p2pfl_amd.config.config import Config
+    d = default_participant()
+    if section is None:
+        d[key] = value
+    else:
+        d[section][key] = value
+    with pytest.raises(ValueError):
+        Config.validate(d)
+
+
+def test_scenario_wide_validation():
+    from p2pfl_amd.config.schema import validate_scenario
+    parts = _participants(4)
+    assert [v.device.idx for v in validate_scenario(parts)] == [0, 1, 2, 3]
+    two_starts = _participants(4)
+    two_starts[2]["device_args"]["start"] = True
+    same_port = _participants(4)
+    same_port[1]["network_args"]["port"] = 45000
+    self_nb = _participants(4)
+    self_nb[1]["network_args"]["neighbors"] += " 127.0.0.1:45001"
+    mixed = _participants(4)
+    mixed[3]["scenario_args"]["federation"] = "CFL"
+    cfl = _participants(4)
+    for p in cfl:
+        p["scenario_args"]["federation"] = "CFL"       # nobody is the server
+    for bad in (two_starts, same_port, self_nb, mixed, cfl, []):
+        with pytest.raises(ValueError):
+            validate_scenario(bad)

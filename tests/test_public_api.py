@@ -1,0 +1,100 @@
+"""the public Python signatures a user of the reference relies on stay importable under the same
+module paths (package name aside) with the same positional order and defaults."""
+import importlib
+import inspect
+
+import pytest
+
+API = [
+    # (module, attribute, leading parameters in order, {parameter: default})
+    ("node", "Node", ["idx", "experiment_name", "model", "data", "hostdemo", "host", "port", "config", "learner", "encrypt"],
+     {"hostdemo": None, "host": "127.0.0.1", "port": None, "encrypt": False}),                       # node.py:77-89
+    ("base_node", "BaseNode", ["experiment_name", "hostdemo", "host", "port", "encrypt", "config"],
+     {"hostdemo": None, "host": "127.0.0.1", "port": None, "encrypt": False, "config": None}),        # base_node.py:55
+    ("config.config", "Config", ["entity", "topology_config_file", "participant_config_file"],
+     {"topology_config_file": None, "participant_config_file": None}),                                  # config.py:30
+    ("utils.topologymanager", "TopologyManager", ["scenario_name", "n_nodes", "b_symmetric", "undirected_neighbor_num", "topology"],
+     {"scenario_name": None, "n_nodes": 5, "b_symmetric": True, "undirected_neighbor_num": 5, "topology": None}),
+    ("learning.aggregators.fedavg", "FedAvg", ["node_name", "config"], {"node_name": "unknown", "config": None}),
+    ("learning.pytorch.lightninglearner", "LightningLearner", ["model", "data", "config", "logger"],
+     {"config": None, "logger": None}),                                                                 # lightninglearner.py:49
+]
+MODELS = [("learning.pytorch.mnist.models.mlp", "MNISTModelMLP"), ("learning.pytorch.mnist.models.cnn", "MNISTModelCNN"),
+          ("learning.pytorch.femnist.models.cnn", "FEMNISTModelCNN"),
+          ("learning.pytorch.syscall.models.mlp", "SyscallModelMLP"),
+          ("learning.pytorch.syscall.models.autoencoder", "SyscallModelAutoencoder"),
+          ("learning.pytorch.syscall.models.svm", "SyscallModelSGDOneClassSVM"),
+          ("learning.pytorch.cifar10.models.resnet", "CIFAR10ModelResNet"),
+          ("learning.pytorch.cifar10.models.fastermobilenet", "FasterMobileNet"),
+          ("learning.pytorch.cifar10.models.simplemobilenet", "SimpleMobileNetV1"),
+          ("learning.pytorch.wadi.models.mlp", "WADIModelMLP")]
+DATA = [("learning.pytorch.mnist.mnist", "MNISTDataModule"), ("learning.pytorch.femnist.femnist", "FEMNISTDataModule"),
+        ("learning.pytorch.cifar10.cifar10", "CIFAR10DataModule"), ("learning.pytorch.syscall.syscall", "SYSCALLDataModule"),
+        ("learning.pytorch.wadi.wadi", "WADIDataModule")]
+
+
+def _get(mod, attr):
+    return getattr(importlib.import_module("p2pfl_amd." + mod), attr)
+
+
+@pytest.mark.parametrize("mod,attr,order,defaults", API, ids=[a[1] for a in API])
+def test_constructor_signatures(mod, attr, order, defaults):
+    params = inspect.signature(_get(mod, attr)).parameters
+    assert list(params)[:len(order)] == order
+    for name, d in defaults.items():
+        assert params[name].default == d, name
+
+
+def test_node_defaults_are_the_config_and_learner_classes():
+    from p2pfl_amd.config.config import Config
+    from p2pfl_amd.learning.pytorch.lightninglearner import LightningLearner
+    p = inspect.signature(_get("node", "Node")).parameters
+    assert p["config"].default is Config and p["learner"].default is LightningLearner
+
+
+@pytest.mark.parametrize("mod,attr", MODELS, ids=[m[1] for m in MODELS])
+def test_model_constructor_convention(mod, attr):
+    """Model(in_channels, out_channels, learning_rate, metrics=None, confusion_matrix=None, seed=None) - mlp.py:108-116"""
+    try:
+        cls = _get(mod, attr)
+    except AttributeError:
+        names = [n for n in dir(importlib.import_module("p2pfl_amd." + mod)) if n[0].isupper()]
+        pytest.fail(f"{mod} has no {attr}; it defines {names}")
+    params = list(inspect.signature(cls).parameters)
+    for name in ("metrics", "confusion_matrix", "seed"):
+        assert name in params, (attr, params)
+    assert "learning_rate" in params or "lr" in params
+
+
+@pytest.mark.parametrize("mod,attr", DATA, ids=[d[1] for d in DATA])
+def test_datamodule_constructor_convention(mod, attr):
+    """DataModule(sub_id, number_sub, batch_size=32, num_workers=4, val_percent=0.1, ...) - mnist.py:52-60"""
+    p = inspect.signature(_get(mod, attr)).parameters
+    assert list(p)[:2] == ["sub_id", "number_sub"]
+    val = 0.01 if attr == "SYSCALLDataModule" else 0.1              # syscall.py:139-146 holds back 1 %
+    assert p["batch_size"].default == 32 and p["val_percent"].default == val and "num_workers" in p
+
+
+def test_learner_template_role_events_protocol_and_entry_points():
+    learner = _get("learning.learner", "NodeLearner")
+    template = {"set_model", "set_data", "encode_parameters", "decode_parameters", "check_parameters", "set_parameters",
+                "get_parameters", "set_epochs", "fit", "interrupt_fit", "evaluate", "log_validation_metrics",
+                "get_num_samples", "init", "close", "finalize_round", "create_trainer"}       # learner.py:24-177
+    assert template <= {m for m in dir(learner) if not m.startswith("_")}
+    role = _get("role", "Role")
+    assert (role.TRAINER, role.AGGREGATOR, role.PROXY, role.IDLE, role.SERVER) == \
+        ("trainer", "aggregator", "proxy", "idle", "server")                                  # role.py:20-36
+    proto = _get("communication_protocol", "CommunicationProtocol")
+    for kind in ("beat", "stop", "connect", "connect_to", "start_learning", "stop_learning", "vote_train_set",
+                 "models_aggregated", "models_ready", "metrics", "model_initialized", "params", "role",
+                 "transfer_leadership"):
+        assert callable(getattr(proto, f"build_{kind}_msg")), kind
+    assert callable(proto.process_message)
+    obs = importlib.import_module("p2pfl_amd.utils.observer")
+    assert all(hasattr(obs, n) for n in ("Events", "Observable", "Observer"))
+    ctrl = _get("controller", "Controller")
+    assert callable(ctrl.start) and callable(ctrl.load_configurations_and_start_nodes)
+    assert list(inspect.signature(ctrl).parameters) == ["args"]
+    assert inspect.signature(_get("node_start", "main")).parameters == {}                    # argv[1] = participant json
+    agg = _get("learning.aggregators.fedavg", "FedAvg")
+    assert list(inspect.signature(agg.aggregate).parameters)[:2] == ["self", "models"]

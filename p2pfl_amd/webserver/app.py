@@ -523,6 +523,26 @@ def fedstellar_statistics_download(scenario_name):
     return send_file(mem, mimetype="application/zip", as_attachment=True, download_name=f"{scenario_name}_metrics.zip")
 
 
+@app.route("/scenario/<scenario_name>/scenario.json")
+def fedstellar_scenario_file(scenario_name):
+    """The whole scenario as ONE document (config/scenario.py: defaults + per-node deltas), packed from the
+    participant files the controller keeps - what the batched launcher takes instead of N files. Tokens and
+    credentials never leave: ``controller_token``, device passwords and W&B keys are blanked."""
+    if "user" not in session:
+        return abort(401)
+    from ..config.scenario import pack_scenario, read_participant_files
+    parts = read_participant_files(_under(app.config["config_dir"], scenario_name))
+    if not parts:
+        return abort(404)
+    for p in parts:
+        p.get("scenario_args", {}).pop("controller_token", None)
+        if "password" in p.get("device_args", {}):
+            p["device_args"]["password"] = ""
+        if "wandb_apikey" in p.get("tracking_args", {}):
+            p["tracking_args"]["wandb_apikey"] = ""
+    return jsonify(pack_scenario(parts))
+
+
 # ------------------------------------------------------------------ deployment
 @app.route("/scenario/deployment/")
 def fedstellar_scenario_deployment():

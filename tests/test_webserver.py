@@ -183,6 +183,16 @@ def test_deployment_run_builds_scenario_and_calls_launcher(web, monkeypatch):
     assert p1["network_args"]["port"] == 47001 and len(p1["network_args"]["neighbors"].split()) == 2      # ring
     assert p1["scenario_args"]["name"] == name and p1["device_args"]["uid"]
     assert appmod.db.get_running_scenario()[0] == name
+    # the whole scenario as one document (config/scenario.py), without the ingest token or credentials
+    from p2pfl_amd.config.scenario import expand_scenario
+    doc = c.get(f"/scenario/{name}/scenario.json")
+    assert doc.status_code == 200
+    parts = expand_scenario(doc.get_json())
+    assert len(parts) == 3 and [p["network_args"]["port"] for p in parts] == [47000, 47001, 47002]
+    assert all("controller_token" not in p["scenario_args"] and p["device_args"]["password"] == "" for p in parts)
+    assert parts[1]["network_args"]["neighbors"] == p1["network_args"]["neighbors"]
+    assert (cdir / "scenario.json").exists()                     # written by the controller beside the participant files
+    assert c.get("/scenario/nope/scenario.json").status_code == 404
     # stop, re-run from the stored controller.json, remove
     assert c.get(f"/scenario/{name}/stop").status_code == 302
     assert appmod.db.get_running_scenario() is None

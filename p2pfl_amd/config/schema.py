@@ -120,7 +120,7 @@ class TrackingArgs:
     wandb_entity: str = ""
 
     def check(self):
-        if self.local_tracking not in ("csv", "web", "tensorboard", ""):
+        if self.local_tracking not in ("csv", "web", "tensorboard", "none", ""):
             raise ValueError(f"tracking_args.local_tracking: {self.local_tracking!r} is neither 'csv' nor 'web'")
 
 

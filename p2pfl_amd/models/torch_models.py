@@ -55,71 +55,21 @@ class FederatedModule(nn.Module):
         return torch.optim.SGD(self.parameters(), lr=o.lr, momentum=o.momentum, weight_decay=o.weight_decay)
 
 
-class MNISTModelMLP(FederatedModule):
-    """784-256-128-C MLP, log-softmax output (reference mnist/models/mlp.py:144-162)."""
-    spec_factory = staticmethod(specs.mnist_mlp)
-
-    def __init__(self, in_channels=1, out_channels=10, learning_rate=1e-3, metrics=None,
-                 confusion_matrix=None, seed=None):
-        super().__init__(in_channels, out_channels, learning_rate, metrics, confusion_matrix, seed)
-        self.l1 = nn.Linear(28 * 28, 256)
-        self.l2 = nn.Linear(256, 128)
-        self.l3 = nn.Linear(128, out_channels)
-
-    def forward(self, x):
-        x = x.reshape(x.shape[0], -1)
-        x = torch.relu(self.l1(x))
-        x = torch.relu(self.l2(x))
-        return torch.log_softmax(self.l3(x), dim=1)
+# The three spec'd families are defined under the reference's module paths; they are resolved lazily here so that either
+# module can be imported first.
+_LAZY = {"MNISTModelMLP": "p2pfl_amd.learning.pytorch.mnist.models.mlp",
+         "MNISTModelCNN": "p2pfl_amd.learning.pytorch.mnist.models.cnn",
+         "FEMNISTModelCNN": "p2pfl_amd.learning.pytorch.femnist.models.cnn"}
+_BY_SPEC = {"mnist-mlp": "MNISTModelMLP", "mnist-cnn": "MNISTModelCNN", "femnist-cnn": "FEMNISTModelCNN"}
 
 
-class MNISTModelCNN(FederatedModule):
-    """conv5x5(1->32)-pool-conv5x5(32->64)-pool-fc2048-fc C (reference mnist/models/cnn.py:134-158).
-
-    The reference ``forward`` returns its input (cnn.py:159); this one returns the logits.
-    """
-    spec_factory = staticmethod(specs.mnist_cnn)
-
-    def __init__(self, in_channels=1, out_channels=10, learning_rate=1e-3, metrics=None,
-                 confusion_matrix=None, seed=None):
-        super().__init__(in_channels, out_channels, learning_rate, metrics, confusion_matrix, seed)
-        self.conv1 = nn.Conv2d(in_channels, 32, kernel_size=5, padding=2)
-        self.conv2 = nn.Conv2d(32, 64, kernel_size=5, padding=2)
-        self.l1 = nn.Linear(7 * 7 * 64, 2048)
-        self.l2 = nn.Linear(2048, out_channels)
-
-    def forward(self, x):
-        x = x.reshape(-1, 1, 28, 28)
-        x = F.max_pool2d(torch.relu(self.conv1(x)), 2, 2)
-        x = F.max_pool2d(torch.relu(self.conv2(x)), 2, 2)
-        x = x.reshape(x.shape[0], -1)
-        x = torch.relu(self.l1(x))
-        return self.l2(x)
-
-
-class FEMNISTModelCNN(FederatedModule):
-    """conv7x7(1->32)-pool-conv3x3(32->64)-pool-fc C, SGD+momentum
-    (reference femnist/models/cnn.py:136-157)."""
-    spec_factory = staticmethod(specs.femnist_cnn)
-
-    def __init__(self, in_channels=1, out_channels=62, learning_rate=1e-3, metrics=None,
-                 confusion_matrix=None, seed=None):
-        super().__init__(in_channels, out_channels, learning_rate, metrics, confusion_matrix, seed)
-        self.conv1 = nn.Conv2d(in_channels, 32, kernel_size=7, padding=3)
-        self.conv2 = nn.Conv2d(32, 64, kernel_size=3, padding=1)
-        self.out = nn.Linear(7 * 7 * 64, out_channels)
-
-    def forward(self, x):
-        x = x.reshape(-1, 1, 28, 28)
-        x = F.max_pool2d(torch.relu(self.conv1(x)), 2, 2)
-        x = F.max_pool2d(torch.relu(self.conv2(x)), 2, 2)
-        x = x.reshape(x.shape[0], -1)
-        return self.out(x)
-
-
-_BY_SPEC = {"mnist-mlp": MNISTModelMLP, "mnist-cnn": MNISTModelCNN, "femnist-cnn": FEMNISTModelCNN}
+def __getattr__(name):
+    if name in _LAZY:
+        import importlib
+        return getattr(importlib.import_module(_LAZY[name]), name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 
 def module_for_spec(spec: specs.ModelSpec, seed=None) -> FederatedModule:
-    cls = _BY_SPEC[spec.name]
+    cls = __getattr__(_BY_SPEC[spec.name])
     return cls(out_channels=spec.num_classes, learning_rate=spec.optim.lr, seed=seed)

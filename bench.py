@@ -110,6 +110,10 @@ def main() -> None:
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single-stream schedule (A/B against the two-stream pipeline)")
     ap.add_argument("--cpu", action="store_true", help="debug: run on the CPU with gloo")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="rehearsal of a multi-rank run on a ONE-GPU box: every rank uses device 0 and the ranks talk "
+                         "gloo (RCCL cannot put two ranks on one device); exercises the plan / staging / FedAvg of the "
+                         "N-rank scenario at full size, not the fabric - the output is labelled and is no benchmark")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--split-nodes", type=int, default=100,
                     help="data shards are sized as in an N-node split of MNIST (reference mnist.py:100-118)")
@@ -131,13 +135,16 @@ def main() -> None:
         device = torch.device("cpu")
         args.impl = "eager"
     else:
+        if args.rehearse_on_one_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
+    host_pg = args.cpu or args.rehearse_on_one_gpu          # gloo: scalars for the final reduction stay on the host
     pg = None
     if world > 1 or os.environ.get("P2PFL_FORCE_PG"):      # P2PFL_FORCE_PG: 1-rank RCCL communicator (smoke test of the multi-rank path)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if args.cpu else "nccl", rank=rank, world_size=world,
-                                **({} if args.cpu else {"device_id": device}))
+        dist.init_process_group("gloo" if host_pg else "nccl", rank=rank, world_size=world,
+                                **({} if host_pg else {"device_id": device}))
         pg = dist.group.WORLD
 
     n_nodes = args.nodes_per_gpu * world if args.scaling == "weak" else args.nodes_per_gpu
@@ -211,7 +218,7 @@ def main() -> None:
             ref_samples += fed.run_round(sync_timing=False).train_samples
         sync()
         ref_elapsed = time.perf_counter() - t1
-        ref = torch.tensor([ref_elapsed, float(ref_samples)], dtype=torch.float64, device=device)
+        ref = torch.tensor([ref_elapsed, float(ref_samples)], dtype=torch.float64, device="cpu" if host_pg else device)
         if pg is not None:
             tm = ref[:1].clone()
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -222,7 +229,7 @@ def main() -> None:
                    "value": ref_samples / ref_elapsed, "unit": "samples/s",
                    "note": "same scenario, every matrix product on v_mfma_f32_32x32x2_f32; measured after the timed region"}
 
-    stats = torch.tensor([elapsed, float(samples)], dtype=torch.float64, device=device)
+    stats = torch.tensor([elapsed, float(samples)], dtype=torch.float64, device="cpu" if host_pg else device)
     if pg is not None:
         tmax = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -232,7 +239,8 @@ def main() -> None:
     if rank == 0:
         sps = samples / elapsed
         steps_per_epoch = -(-n_tr // args.batch_size)
-        base = eager_baseline_samples_per_sec() if args.config is None and args.impl == "hip" else None
+        base = (eager_baseline_samples_per_sec()
+                if args.config is None and args.impl == "hip" and not args.rehearse_on_one_gpu else None)
         out = {
             "metric": "aggregate client samples/sec (federated rounds, MNIST CNN, 100 nodes per GPU)"
             if args.config is None and spec.name == "mnist-cnn" and args.nodes_per_gpu == 100
@@ -259,6 +267,8 @@ def main() -> None:
                 "train_samples_per_node": n_tr, "optimizer_steps_per_round": steps_per_epoch * args.epochs,
                 "seq_len": None, "parallelism": f"fdp{world}x{n_local}", "encrypt": args.encrypt,
                 "churn": args.churn, "preset": args.config, "virtual_devices": args.virtual_devices,
+                **({"rehearsal": "all ranks on ONE GPU over gloo: a functional rehearsal, not a scaling measurement"}
+                   if args.rehearse_on_one_gpu else {}),
                 "precision_policy": {
                     "fp32": "fp32 storage / accumulation / optimizer state; fp32 operands on v_mfma_f32_32x32x2_f32, stage-2 "
                             "convolutions via an exact 3-term bf16 split of both operands (6 bf16 MFMAs per product "

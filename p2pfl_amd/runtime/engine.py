@@ -815,8 +815,102 @@ class HipEngine(ShardEngine):
             if self.val_x is not None:
                 self._eval_pass(self.val_x, self.val_y, "Validation")
 
+    # ------------------------------------------------------------------ client groups beside each other
+    def _group_views(self, G: int):
+        """``G`` shallow copies of this engine that each see one contiguous 1/G of the clients (every per-client
+        buffer sliced along the client dimension), so the per-step methods can be run per group."""
+        import copy
+        keep = self.__dict__.setdefault("_group_keep", {})
+        bounds = [(g * self.K) // G for g in range(G + 1)]
+        views = []
+        for g in range(G):
+            sl = slice(bounds[g], bounds[g + 1])
+            v = copy.copy(self)
+            v.K = sl.stop - sl.start
+            v._rows = sl
+            for name in ("params", "grads", "m", "v", "karange", "train_x", "train_y"):
+                t = getattr(self, name, None)
+                if t is not None:
+                    setattr(v, name, t[sl])
+            v.act = [a[sl] for a in self.act]
+            v.dact = [a[sl] for a in self.dact]
+            v.code = [None if c is None else c[sl] for c in self.code]
+            v._act_pp = [a[sl] for a in self._act_pp]
+            v.wprep = {i: w[sl] for i, w in self.wprep.items()}
+            v.stats = {ph: PhaseStats(st.loss_sum[sl], st.correct[sl], st.count[sl], st.confusion[sl])
+                       for ph, st in self.stats.items()}
+            v._step_log = None if self._step_log is None else self._step_log[:, :, sl]
+            # buffers with static addresses of their own (baked into the captured graph): kept on the engine
+            own = keep.setdefault((G, g), {"nv": {}, "fwd": {}, "w2": None})
+            if own["w2"] is None:
+                own["w2"] = {i: self.hip.conv2_wgrad_scratch(v.K, self.B, l.ksize, self.device)
+                             for i, l in enumerate(self.spec.layers) if l.kind == "conv2pool"}
+            v._nv_cache, v._fwd_scratch, v.w2_scratch = own["nv"], own["fwd"], own["w2"]
+            v._wgrad_ev = None
+            views.append(v)
+        return views
+
+    def _train_body_groups(self, epochs: int, steps: int, n: int, G: int) -> None:
+        """The clients as ``G`` independent groups whose steps alternate on the two streams:
+
+            main : [A dense fwd + loss + fused update/dgrad][B dense ...........................][A ...
+            side :                                          [A conv bwd, small Adam, conv fwd   ][B conv ...
+
+        No client depends on another during local training, so while the HBM-bound dense chain of one group streams
+        its weights, the matrix-pipe-bound convolution chain of the other group has the matrix cores - an overlap the
+        update and the convolutions of the SAME clients cannot have once the update hands out the data gradient itself
+        (tools/probe/halves_probe.py: 4.93 -> 4.62 ms per step for 100 MNIST-CNN clients; CU-masked streams lose).
+        """
+        main, side = torch.cuda.current_stream(), self._side
+        B = self.B
+        views = self._group_views(G)
+        last_valid = n - (steps - 1) * B
+        for ph in ("Train", "Validation"):
+            self.stats[ph].zero_()
+        done = [None] * G                    # side stream finished the convolution chain (next forward included) of group g
+        t = 0
+        for e in range(epochs):
+            if e == epochs - 1 and epochs > 1:
+                for ph in ("Train", "Validation"):
+                    self.stats[ph].zero_()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for g, v in enumerate(views):
+                    v._conv_forward(v.train_x, self._perm_buf[e, v._rows, :B], v._act_pp[t & 1])
+                    done[g] = torch.cuda.Event()
+                    done[g].record(side)
+            for s in range(steps):
+                t += 1
+                for g, v in enumerate(views):
+                    sidx = self._perm_buf[e, v._rows, s * B:(s + 1) * B]
+                    nv = v._nv(last_valid if s == steps - 1 else B)
+                    main.wait_event(done[g])
+                    v._dense_step(v._act_pp[(t - 1) & 1], v.train_y, sidx, nv, t, side)     # releases side after the update
+                    with torch.cuda.stream(side):
+                        v._conv_backward(v.train_x, sidx)
+                        v._optim_step(t)
+                        if s + 1 < steps:
+                            v._conv_forward(v.train_x, self._perm_buf[e, v._rows, (s + 1) * B:(s + 2) * B], v._act_pp[t & 1])
+                        done[g] = torch.cuda.Event()
+                        done[g].record(side)
+            main.wait_stream(side)
+            if self.val_x is not None:
+                self._eval_pass(self.val_x, self.val_y, "Validation")
+        self._step_pos = views[0]._step_pos
+
+    def _groups(self) -> int:
+        """Client groups of the two-stream schedule: 2 when every group still takes the fused update + data gradient
+        (>= 41 clients each, see ops/hip.py) - ``P2PFL_GROUPS`` overrides (1: one group, the plain pipeline)."""
+        env = os.environ.get("P2PFL_GROUPS")
+        if env is not None:
+            return max(1, min(int(env), self.K))
+        return 2 if (self._fuse_dgrad and self.K >= 82 and self.spec.optim.kind == "adam") else 1
+
     def _train(self, epochs: int, steps: int, n: int) -> None:
         self._step_pos = 0
+        if self.overlap and not os.environ.get("P2PFL_INORDER") and self._groups() > 1:
+            self._train_body_groups(epochs, steps, n, self._groups())
+            return
         # The two-stream schedule runs eagerly (warm-up, use_graph=False) exactly as it is captured: the stall that
         # once forced eager launches onto the in-order schedule came from the side stream's priority (see __init__).
         if self.overlap and not os.environ.get("P2PFL_INORDER"):

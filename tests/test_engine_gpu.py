@@ -184,6 +184,58 @@ def test_pipelined_schedule_matches_single_stream():
         assert torch.allclose(tl, out[0][1], atol=1e-2) and torch.allclose(vl, out[0][2], atol=1e-2)
 
 
+def test_client_groups_match_the_plain_pipeline(monkeypatch):
+    """Client groups beside each other (84 clients = 2 x 42: every group still takes the fused update + data gradient;
+    3 x 28: the groups fall back to the separate data gradient) == one group, captured and launched eagerly."""
+    import gc
+    from p2pfl_amd.datasets.synthetic import synthetic_shards
+    from p2pfl_amd.models.specs import get_spec
+    from p2pfl_amd.runtime.engine import HipEngine
+    spec = get_spec("mnist-cnn")
+    K = 84
+    data = synthetic_shards(K, 80, 16, 40, spec.num_classes, seed=5, device="cuda")
+    init = HipEngine(spec, K, "cuda", seed=7, use_graph=False)
+    init.init_params(identical=False)
+    p0 = init.params.clone()
+    del init
+    out = []
+    for groups, graph in (("1", True), ("1", False), ("2", True), ("2", False), ("3", True)):
+        monkeypatch.setenv("P2PFL_GROUPS", groups)
+        h = HipEngine(spec, K, "cuda", seed=7, use_graph=graph, log_steps=True)
+        assert h.overlap and h._groups() == int(groups)
+        h.init_params(identical=False)
+        h.set_data(*data)
+        h.fit(2)
+        r = h.fit(2)     # replay of the captured graph
+        torch.cuda.synchronize()
+        out.append((h.params - p0, r["Train"]["loss"].clone(), r["Validation"]["loss"].clone(),
+                    r["Train"]["count"].clone(), h.step_losses().clone()))
+        h.close()
+        del h
+        gc.collect()
+        torch.cuda.empty_cache()
+    monkeypatch.delenv("P2PFL_GROUPS")
+    h = HipEngine(spec, K, "cuda", seed=7)
+    assert h._groups() == 2                      # the default for >= 82 Adam clients under the fp32 policy
+    assert HipEngine(spec, 40, "cuda", seed=7)._groups() == 1
+    d0, tl0, vl0, c0, sl0 = out[0]
+    noise = ((out[1][0] - d0).norm(dim=1) / d0.norm(dim=1)).max().item()       # one group, graph vs eager launches
+    print(f"per-client update difference between two runs of the SAME schedule: up to {noise:.3g}")
+    # losses (16 validation samples per client) move with those flips: tolerances from the same-schedule pair
+    tol = [max(5e-2, 4 * (out[1][i] - out[0][i]).abs().max().item()) for i in (1, 2, 4)]
+    for d, tl, vl, c, sl in out[1:]:
+        # float atomics in the conv1 weight gradient: runs are not bit-equal, and Adam turns a flipped tiny gradient
+        # into an lr-sized step - a few clients differ by percents between ANY two runs, most by 1e-5; a schedule bug
+        # would move every client of a group
+        per_client = (d - d0).norm(dim=1) / d0.norm(dim=1)
+        assert per_client.median().item() < 1e-3, per_client.median().item()
+        assert ((d - d0).norm() / d0.norm()).item() < 0.05
+        assert (tl - tl0).abs().max().item() <= tol[0] and (vl - vl0).abs().max().item() <= tol[1]
+        assert ((vl - vl0).abs() < 1e-5).float().mean().item() > 0.6        # most clients: the same numbers to the last bits
+        assert torch.equal(c, c0)
+        assert sl.shape == sl0.shape and (sl - sl0).abs().max().item() <= tol[2]
+
+
 # ---------------------------------------------------------------------------------------------------------
 # Two ranks sharing the one GPU of the test box (gloo, rows staged through the host): the rank-local index
 # math of the exchange plan + the HIP reduce over local and staged remote rows + per-link device AES must

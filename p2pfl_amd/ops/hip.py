@@ -131,6 +131,7 @@ class _Sig:
     p2pfl_softmax_ce = [P, L, P, L, P, L, P, L, P, P, P, P, P, L, I, I, I, P]
     p2pfl_zero_rows = [P, L, I, I, P]
     p2pfl_adam_step = [P, P, P, P, L, L, I, F, F, F, F, F, I, P, P]
+    p2pfl_adam_step2 = [P, P, P, P, L, L, L, L, I, F, F, F, F, F, I, P, P]
     p2pfl_sgdm_step = [P, P, P, L, L, I, F, F, F, P]
     p2pfl_fedavg = [P, L, I, P, L, P, L, P, P, P, P, P, I, L, P]
     p2pfl_fedavg_inplace = [P, L, I, P, L, I, P, P, P, P, P, I, L, P]
@@ -430,6 +431,19 @@ def adam_step(p, g, m, v, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=
     _chk(load().p2pfl_adam_step(_t(p).data_ptr(), _t(g).data_ptr(), _t(m).data_ptr(), _t(v).data_ptr(), cs, n, K,
                                 lr, beta1, beta2, eps, weight_decay, t,
                                 None if bc is None else _t(bc).data_ptr(), _stream()), "adam_step")
+
+
+def adam_step_ranges(p, g, m, v, ranges, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, t: int,
+                     bc=None) -> None:
+    """Adam step over the column ranges ``[(a0, b0), (a1, b1)]`` (a0 < b0 <= a1 < b1) of [K, P] slabs in ONE launch."""
+    (a0, b0), (a1, b1) = ranges
+    assert 0 <= a0 < b0 <= a1 < b1 <= p.shape[1]
+    cs = p.stride(0)
+    assert g.stride(0) == cs and m.stride(0) == cs and v.stride(0) == cs and g.shape == p.shape
+    _chk(load().p2pfl_adam_step2(_t(p[:, a0:]).data_ptr(), _t(g[:, a0:]).data_ptr(), _t(m[:, a0:]).data_ptr(),
+                                 _t(v[:, a0:]).data_ptr(), cs, b0 - a0, a1 - b0, b1 - a1, p.shape[0], lr, beta1, beta2,
+                                 eps, weight_decay, t, None if bc is None else _t(bc).data_ptr(), _stream()),
+         "adam_step_ranges")
 
 
 def sgdm_step(p, g, buf, *, lr, momentum=0.9, weight_decay=0.0) -> None:

@@ -610,6 +610,8 @@ class HipEngine(ShardEngine):
 
     def _optim_step(self, step_index: int) -> None:
         o = self.spec.optim
+        # (one launch over both ranges - hip.adam_step_ranges - is 2.8 ms per headline round SLOWER beside the other
+        # group's update than these two: 256.4 vs 253.5 ms, measured twice alternating)
         if o.kind == "adam":
             for a, b in self._adam_ranges:   # everything the fused wgrad+Adam kernels do not own
                 self.hip.adam_step(self.params[:, a:b], self.grads[:, a:b], self.m[:, a:b], self.v[:, a:b],
@@ -867,6 +869,7 @@ class HipEngine(ShardEngine):
         last_valid = n - (steps - 1) * B
         for ph in ("Train", "Validation"):
             self.stats[ph].zero_()
+        cores = bool(os.environ.get("P2PFL_GROUPS_CORES"))      # experiment: small-footprint convolution variants
         done = [None] * G                    # side stream finished the convolution chain (next forward included) of group g
         t = 0
         for e in range(epochs):
@@ -887,10 +890,11 @@ class HipEngine(ShardEngine):
                     main.wait_event(done[g])
                     v._dense_step(v._act_pp[(t - 1) & 1], v.train_y, sidx, nv, t, side)     # releases side after the update
                     with torch.cuda.stream(side):
-                        v._conv_backward(v.train_x, sidx)
+                        v._conv_backward(v.train_x, sidx, coresident=cores)
                         v._optim_step(t)
                         if s + 1 < steps:
-                            v._conv_forward(v.train_x, self._perm_buf[e, v._rows, (s + 1) * B:(s + 2) * B], v._act_pp[t & 1])
+                            v._conv_forward(v.train_x, self._perm_buf[e, v._rows, (s + 1) * B:(s + 2) * B], v._act_pp[t & 1],
+                                            coresident=cores)
                         done[g] = torch.cuda.Event()
                         done[g].record(side)
             main.wait_stream(side)

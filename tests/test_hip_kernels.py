@@ -448,6 +448,40 @@ def test_softmax_ce(C, B, nv):
         assert (cm[k] == ref_cm).all()
 
 
+def test_adam_two_ranges_in_one_launch_match_torch_and_leave_the_gap_alone():
+    h = hip()
+    K, P = 5, 4096
+    ranges = [(64, 1088), (3072, 4032)]
+    p = torch.randn(K, P, device=DEV)
+    m, v = torch.zeros(K, P, device=DEV), torch.zeros(K, P, device=DEV)
+    p0 = p.clone()
+    cols = torch.cat([torch.arange(a, b) for a, b in ranges]).to(DEV)
+    ref_p = [torch.nn.Parameter(p[k, cols].clone()) for k in range(K)]
+    opt = torch.optim.Adam(ref_p, lr=1e-3)
+    bc = torch.zeros(2, device=DEV)
+    for t in range(1, 6):
+        g = torch.randn(K, P, device=DEV)
+        if t % 2:
+            h.adam_step_ranges(p, g, m, v, ranges, lr=1e-3, t=t)
+        else:
+            bc.copy_(torch.tensor([1 / (1 - 0.9 ** t), 1 / (1 - 0.999 ** t) ** 0.5]))
+            h.adam_step_ranges(p, g, m, v, ranges, lr=1e-3, t=1, bc=bc)
+        for k in range(K):
+            ref_p[k].grad = g[k, cols].clone()
+        opt.step()
+    for k in range(K):
+        assert torch.allclose(p[k, cols], ref_p[k].detach(), atol=1e-6, rtol=1e-5)
+    rest = torch.ones(P, dtype=torch.bool, device=DEV)
+    rest[cols] = False
+    assert torch.equal(p[:, rest], p0[:, rest]) and not m[:, rest].any() and not v[:, rest].any()
+    with pytest.raises(Exception):
+        h.adam_step_ranges(p, g, m, v, [(64, 1088), (1000, 2000)], lr=1e-3, t=1)      # overlapping ranges
+    # the same on a client slice of the slabs (what a client group of the engine passes)
+    q = p.clone()
+    h.adam_step_ranges(q[2:4], g[2:4], m[2:4], v[2:4], ranges, lr=1e-3, t=9)
+    assert torch.equal(q[:2], p[:2]) and torch.equal(q[4:], p[4:]) and not torch.equal(q[2:4, cols], p[2:4, cols])
+
+
 def test_adam_and_sgd_trajectories():
     h = hip()
     K, n = 3, 1000

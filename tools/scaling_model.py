@@ -19,7 +19,7 @@ from p2pfl_amd.parallel.planner import estimate_exchange_seconds, owner_of, part
 from p2pfl_amd.runtime.slab import ParamLayout  # noqa: E402
 from p2pfl_amd.utils.topologymanager import TopologyManager  # noqa: E402
 
-base_ms = float(sys.argv[1]) if len(sys.argv) > 1 else 270.5
+base_ms = float(sys.argv[1]) if len(sys.argv) > 1 else 253.3
 row_bytes = ParamLayout(get_spec("mnist-cnn")).row_stride * 4
 GATHER_BPS = 2.5e12          # index_select into the send buffer: read + write (measured class: device copy)
 FEDAVG_BPS = 3.6e12          # in-place reduce with staged rows (tools/probe/fedavg_probe.py 350: 14.3 GB in 3.96 ms)

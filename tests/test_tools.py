@@ -40,6 +40,32 @@ def test_round_timeline_splits_a_trace_at_the_fedavg_launches(tmp_path):
     assert abs(total - (4 * 3.61 + 0.1 + 1.2)) < 0.06 and abs(total - busy - idle) < 0.11 and abs(idle - 0.14) < 0.06
 
 
+def test_round_timeline_reports_queues_that_run_beside_each_other(tmp_path):
+    rows = []
+    for rnd in range(3):
+        base = 1000 + rnd * 10000
+        for step in range(2):                                # queue 1: 3 us update; queue 2: 2 us convolution inside it
+            t = base + step * 4000
+            rows.append({"Kernel_Name": "void update_kernel(Args)", "Queue_Id": 1, "Start_Timestamp": t, "End_Timestamp": t + 3000})
+            rows.append({"Kernel_Name": "void conv_kernel(Args)", "Queue_Id": 2, "Start_Timestamp": t + 500, "End_Timestamp": t + 2500})
+        rows.append({"Kernel_Name": "void fedavg_inplace_kernel<64>(Args)", "Queue_Id": 1, "Start_Timestamp": base + 8000,
+                     "End_Timestamp": base + 9000})
+    trace = tmp_path / "t_kernel_trace.csv"
+    with open(trace, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0]))
+        w.writeheader()
+        w.writerows(rows)
+    out = tmp_path / "round.csv"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "round_timeline.py"), str(trace), str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    with open(out) as f:
+        got = {row["kernel"]: row for row in csv.DictReader(f)}
+    assert float(got["busy on queue_id 1"]["total_us"]) == 7.0 and float(got["busy on queue_id 2"]["total_us"]) == 4.0
+    assert float(got["kernels of different queues beside each other"]["total_us"]) == 4.0
+    assert float(got["union of kernel intervals"]["total_us"]) == 7.0
+
+
 def test_scaling_model_plans_the_bench_scenario():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scaling_model.py"), "270"], capture_output=True,
                        text=True, timeout=300)

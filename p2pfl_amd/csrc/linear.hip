@@ -720,12 +720,13 @@ P2PFL_API int p2pfl_linear_wgrad_adam_dgrad(const float* dy, long dy_cs, const f
     if (prec == PREC_BF16 || B > GEMM_BK || (In & 3) || (w_cs & 3) || (dx_cs & 3) || ((uintptr_t)w & 15) ||
         ((uintptr_t)mw & 15) || ((uintptr_t)vw & 15) || ((uintptr_t)dx & 15) || K > 65535)
         return -4;
-    // a block walks ALL row tiles of its column strip: with few clients there are too few strips to fill the chip
-    // (10 clients: 250 blocks for 512 slots - measured 430 -> 470 ms per cnn10-fully round); decline below two full
-    // rounds of resident workgroups unless asked (force: tests)
+    // a block walks ALL row tiles of its column strip: with few clients there are too few strips to fill the chip.
+    // Decline below three workgroups per CU unless asked (force: tests) - measured with the 8-row ring (one resident
+    // workgroup per CU), MNIST-CNN l1, rounds with / without: 10 clients 359 / 344 ms, 20: 64.6 / 61.6, 30: 82.6 / 83.4,
+    // 40: 108.2 / 112.1 (tools/probe/force_dgrad.sh)
     const char* fe = getenv("P2PFL_FUSE_DGRAD_FORCE");
     const bool force = fe && atoi(fe) != 0;
-    if (!force && (long)cdiv(In + 1, 128) * K < 4L * num_cus()) return -4;
+    if (!force && (long)cdiv(In + 1, 128) * K < 3L * num_cus()) return -4;
     const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
     WgradAdamArgs a{dy, dy_cs, x, x_cs, w, mw, vw, w_cs, b, mb, vb, b_cs, B, In, Out,
                     AdamHyper{lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),

@@ -904,7 +904,7 @@ class HipEngine(ShardEngine):
 
     def _groups(self) -> int:
         """Client groups of the two-stream schedule: 2 when every group still takes the fused update + data gradient
-        (>= 41 clients each, see ops/hip.py) - ``P2PFL_GROUPS`` overrides (1: one group, the plain pipeline)."""
+        (two groups of >= 41 clients is what was measured; the kernel itself is taken from 31 clients on) - ``P2PFL_GROUPS`` overrides (1: one group, the plain pipeline)."""
         env = os.environ.get("P2PFL_GROUPS")
         if env is not None:
             return max(1, min(int(env), self.K))

@@ -904,11 +904,11 @@ class HipEngine(ShardEngine):
 
     def _groups(self) -> int:
         """Client groups of the two-stream schedule: 2 when every group still takes the fused update + data gradient
-        (two groups of >= 41 clients is what was measured; the kernel itself is taken from 31 clients on) - ``P2PFL_GROUPS`` overrides (1: one group, the plain pipeline)."""
+        (>= 31 clients each, see csrc/linear.hip; measured from 2 x 32 clients up: tools/probe/groups_k.sh) - ``P2PFL_GROUPS`` overrides (1: one group, the plain pipeline)."""
         env = os.environ.get("P2PFL_GROUPS")
         if env is not None:
             return max(1, min(int(env), self.K))
-        return 2 if (self._fuse_dgrad and self.K >= 82 and self.spec.optim.kind == "adam") else 1
+        return 2 if (self._fuse_dgrad and self.K >= 62 and self.spec.optim.kind == "adam") else 1
 
     def _train(self, epochs: int, steps: int, n: int) -> None:
         self._step_pos = 0

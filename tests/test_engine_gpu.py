@@ -216,7 +216,7 @@ def test_client_groups_match_the_plain_pipeline(monkeypatch):
         torch.cuda.empty_cache()
     monkeypatch.delenv("P2PFL_GROUPS")
     h = HipEngine(spec, K, "cuda", seed=7)
-    assert h._groups() == 2                      # the default for >= 82 Adam clients under the fp32 policy
+    assert h._groups() == 2                      # the default for >= 62 Adam clients under the fp32 policy
     assert HipEngine(spec, 40, "cuda", seed=7)._groups() == 1
     d0, tl0, vl0, c0, sl0 = out[0]
     noise = ((out[1][0] - d0).norm(dim=1) / d0.norm(dim=1)).max().item()       # one group, graph vs eager launches

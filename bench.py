@@ -5,8 +5,12 @@
     evaluate (test shard) -> local training (epochs x ceil(n_train/32) Adam steps, batch 32,
     shuffled, + per-epoch validation) -> model exchange -> FedAvg over each node's train set.
 
-Launch:  python bench.py --gpus 1 --steps K --warmup W
+Launch:  python bench.py --gpus N --steps K --warmup W        (N > 1: this process starts N rank processes itself,
+                                                              one per GPU over RCCL, BEFORE touching the GPU)
          python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+                                                             (an external launcher that sets RANK/WORLD_SIZE)
+A rank exits non-zero when the box has fewer GPUs than ranks (unless --cpu / --rehearse-on-one-gpu); ``n_gpus`` in the
+JSON line is the number of ranks of the process group that really ran (``config.rccl_ranks`` / ``config.backend``).
 
 Scaling is weak by default: every GPU hosts ``--nodes-per-gpu`` (100) federation nodes of one
 N x 100-node random-topology scenario, so N = 1 is exactly the named 100-node configuration.
@@ -30,6 +34,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -87,6 +93,45 @@ def build_topology(kind: str, n: int, seed: int):
     return tm.topology
 
 
+def launch_ranks(n: int, argv) -> int:
+    """``python bench.py --gpus N`` without an external launcher: start N fresh rank processes of this script (one per
+    GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), relay their output - rank 0 prints the one JSON
+    line - and return non-zero if any rank failed. Runs before this process has made a single GPU call, and the ranks
+    are children (never an exec of a process that initialised the GPU)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), P2PFL_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(n, 1) // 2)))
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__), *argv], env=env))
+    rc = 0
+    deadline = None
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0:
+                if rc == 0:
+                    print(f"bench.py: rank {r} of {n} exited with code {code}", file=sys.stderr, flush=True)
+                    deadline = time.monotonic() + 20.0     # its peers are stuck in a collective: give them a moment, then end them
+                rc = rc or (code if code > 0 else 1)
+        if deadline is not None and time.monotonic() > deadline:
+            for r in pending:
+                procs[r].kill()
+            for r in pending:
+                procs[r].wait()
+            break
+        time.sleep(0.05)
+    return rc
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,15 +173,30 @@ def main() -> None:
         for k, v in PRESETS[args.config].items():
             setattr(args, k, v)
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no external launcher: become the launcher (nothing in this process has touched the GPU yet)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; running (and reporting) "
+              f"{world}", file=sys.stderr, flush=True)
     if args.cpu:
         device = torch.device("cpu")
         args.impl = "eager"
     else:
+        n_dev = torch.cuda.device_count()        # counts devices without initialising the GPU
         if args.rehearse_on_one_gpu:
             local_rank = 0
+        elif n_dev < max(world, local_rank + 1):
+            print(f"bench.py: rank {rank}: {world} ranks were asked for but this box has {n_dev} GPU(s); one rank per "
+                  f"GPU is required (use --rehearse-on-one-gpu for a labelled functional rehearsal over gloo, or --cpu)",
+                  file=sys.stderr, flush=True)
+            sys.exit(3)
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
     host_pg = args.cpu or args.rehearse_on_one_gpu          # gloo: scalars for the final reduction stay on the host
@@ -266,6 +326,8 @@ def main() -> None:
                 "global_batch": args.batch_size * n_nodes, "batch_per_node": args.batch_size,
                 "train_samples_per_node": n_tr, "optimizer_steps_per_round": steps_per_epoch * args.epochs,
                 "seq_len": None, "parallelism": f"fdp{world}x{n_local}", "encrypt": args.encrypt,
+                "rccl_ranks": dist.get_world_size() if pg is not None else 1,
+                "backend": (dist.get_backend() if pg is not None else None),
                 "churn": args.churn, "preset": args.config, "virtual_devices": args.virtual_devices,
                 **({"rehearsal": "all ranks on ONE GPU over gloo: a functional rehearsal, not a scaling measurement"}
                    if args.rehearse_on_one_gpu else {}),

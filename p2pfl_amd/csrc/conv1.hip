@@ -196,9 +196,10 @@ struct Conv1WgradArgs {
     const uint8_t* code; long c_cs;
     const float* data; long data_cs;
     const int* sidx;   long sidx_cs;
-    float* dw;         long dw_cs;     // [K][F][KS*KS]  (must be zeroed)
-    float* db;         long db_cs;     // [K][F]         (must be zeroed)
+    float* dw;         long dw_cs;     // [K][F][KS*KS]  (written by the finishing pass, unless it applies the optimizer)
+    float* db;         long db_cs;     // [K][F]
     int B, F;
+    float* part;                       // per-wave partial tiles [K][gridDim.x * 4][2][16][64] (raw accumulator layout)
 };
 
 constexpr int WG_ROWS = 36;     // last row 2*13 + 1 + tap row 7 = 34
@@ -322,18 +323,50 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1WgradArgs a) {
         __syncthreads();
         cur ^= 1;
     }
-    // acc[jn][e] = partial dW[f = mfma_row(e)][tap n = jn*32 + r] of this wave's window rows
-    float* dw = a.dw + c * a.dw_cs;
-    float* db = a.db + c * a.db_cs;
+    // acc[jn][e] = partial dW[f = mfma_row(e)][tap n = jn*32 + r] of this wave's window rows: stored raw (coalesced, no
+    // atomics); conv1_wgrad_finish_kernel adds the partials of a client up in a fixed order - bitwise reproducible
+    float* pw = a.part + (((size_t)c * gridDim.x + blockIdx.x) * 4 + wave) * (2 * 1024);
 #pragma unroll
-    for (int jn = 0; jn < 2; ++jn) {
-        const int n = jn * 32 + r, ky = n >> 3, kx = n & 7;
+    for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int fo = mfma_row(e, lane);
-            if (fo >= a.F) continue;
-            if (n == 63) atomicAdd(db + fo, acc[jn][e]);
-            else if (ky < KS && kx < KS) atomicAdd(dw + fo * KS * KS + ky * KS + kx, acc[jn][e]);
+        for (int e = 0; e < 16; ++e) pw[(jn * 16 + e) * 64 + lane] = acc[jn][e];
+}
+
+// Sum of the per-wave partial tiles of one client, partial by partial in index order, then either the gradient store or
+// the layer's optimizer step (the gradient value is final here, so it never has to reach memory).
+// One block per client, thread = (accumulator register e, lane) of the MFMA tile layout.
+struct Conv1FinishArgs {
+    const float* part; int nparts, njn, tap8;
+    float* dw; long dw_cs; float* db; long db_cs;
+    int F, KS;
+    OptEpi opt;
+};
+
+__global__ __launch_bounds__(1024) void conv1_wgrad_finish_kernel(Conv1FinishArgs a) {
+    const int c = blockIdx.x, lane = threadIdx.x & 63, e = threadIdx.x >> 6;
+    const int f = mfma_row(e, lane), T = a.KS * a.KS;
+    const OptEpi::Scal sc = a.opt.kind ? a.opt.scal() : OptEpi::Scal{0.f, 0.f};
+    const float* p = a.part + (size_t)c * a.nparts * a.njn * 1024 + threadIdx.x;
+    for (int jn = 0; jn < a.njn; ++jn) {
+        float s = 0.f;
+        for (int k = 0; k < a.nparts; ++k) s += p[((size_t)k * a.njn + jn) * 1024];
+        if (f >= a.F) continue;
+        const int n = jn * 32 + (lane & 31);
+        int tap = -1; bool bias = false;
+        if (a.tap8) {
+            const int ky = n >> 3, kx = n & 7;
+            if (n == 63) bias = true;
+            else if (ky < a.KS && kx < a.KS) tap = ky * a.KS + kx;
+        } else {
+            if (n == T) bias = true;
+            else if (n < T) tap = n;
+        }
+        if (bias) {
+            if (a.opt.kind) a.opt.bias(sc, c, f, s);
+            else a.db[c * a.db_cs + f] = s;
+        } else if (tap >= 0) {
+            if (a.opt.kind) a.opt.weight(sc, c, f * T + tap, s);
+            else a.dw[c * a.dw_cs + f * T + tap] = s;
         }
     }
 }
@@ -363,25 +396,51 @@ P2PFL_API int p2pfl_conv1_fwd(const float* data, long data_cs, const int* sidx, 
     P2PFL_RETURN_LAST_ERROR();
 }
 
-P2PFL_API int p2pfl_conv1_wgrad(const float* g, long g_cs, const uint8_t* code, long c_cs,
-                                const float* data, long data_cs, const int* sidx, long sidx_cs,
-                                float* dw, long dw_cs, float* db, long db_cs, int K, int B, int F,
-                                int KS, int prec, hipStream_t stream) {
-    if (prec != PREC_BF16)
-        return conv1_wgrad_f32(g, g_cs, code, c_cs, data, data_cs, sidx, sidx_cs, dw, dw_cs, db, db_cs, K, B, F, KS,
-                               stream);
-    if (K <= 0 || B <= 0 || F <= 0 || F > 32) return -1;
-    // dw/db are accumulated with atomics: the caller zeroes them first (p2pfl_zero_rows).
-    // float4 / word loads of the pooled gradient and the codes of an image
-    if (((uintptr_t)g & 15) || (g_cs & 3) || ((uintptr_t)code & 3) || (c_cs & 3)) return -2;
-    // blocks per client: about 1.5 per CU over the launch, at most one per image (more blocks = more atomics)
-    int splits = cdiv(384, K);     // measured (7x7; 10 / 50 / 100 clients): target 256: 49 / 63 / 107 us, 384: 63 / 63 / 91, 512: 63 / 67 / 87, 768: 63 / 88 / 110, 1536: 64 / 124 / 140
+int conv1_wgrad_finish(const float* part, int nparts, int njn, int tap8, float* dw, long dw_cs, float* db, long db_cs,
+                       int K, int F, int KS, const P2pflOpt* opt, hipStream_t stream) {
+    if (!opt_epi_valid(opt)) return -1;
+    Conv1FinishArgs a{part, nparts, njn, tap8, dw, dw_cs, db, db_cs, F, KS, make_opt_epi(opt)};
+    if (a.opt.kind == 0 && (dw == nullptr || db == nullptr)) return -1;
+    hipLaunchKernelGGL(conv1_wgrad_finish_kernel, dim3(K), dim3(1024), 0, stream, a);
+    P2PFL_RETURN_LAST_ERROR();
+}
+
+// blocks per client of the bf16 kernel: about 1.5 per CU over the launch, at most one per image
+// measured (7x7; 10 / 50 / 100 clients): target 256: 49 / 63 / 107 us, 384: 63 / 63 / 91, 512: 63 / 67 / 87, 768: 63 / 88 / 110, 1536: 64 / 124 / 140
+static int conv1_wgrad_splits(int K, int B) {
+    int splits = cdiv(384, K);
     if (splits > B) splits = B;
     if (splits < 1) splits = 1;
-    Conv1WgradArgs a{g, g_cs, code, c_cs, data, data_cs, sidx, sidx_cs, dw, dw_cs, db, db_cs, B, F};
+    return splits;
+}
+
+// floats of scratch p2pfl_conv1_wgrad needs (the per-wave partial tiles)
+P2PFL_API long p2pfl_conv1_wgrad_scratch(int K, int B, int KS, int prec) {
+    if (K <= 0 || B <= 0) return 0;
+    if (prec != PREC_BF16) return (long)K * conv1_wgrad_f32_splits(K, B) * 4 * ((KS * KS + 1 + 31) / 32) * 1024;
+    return (long)K * conv1_wgrad_splits(K, B) * 4 * 2 * 1024;
+}
+
+// Stage-1 weight / bias gradient. Blocks write per-wave partial tiles into ``scratch`` and a finishing pass adds them up
+// in a fixed order (no atomics: bitwise reproducible) and either stores dw / db or - ``opt`` given - applies the layer's
+// optimizer step right there (dw / db may then be null).
+P2PFL_API int p2pfl_conv1_wgrad(const float* g, long g_cs, const uint8_t* code, long c_cs,
+                                const float* data, long data_cs, const int* sidx, long sidx_cs,
+                                float* dw, long dw_cs, float* db, long db_cs, float* scratch, long scratch_floats,
+                                int K, int B, int F, int KS, int prec, const P2pflOpt* opt, hipStream_t stream) {
+    if (!opt_epi_valid(opt)) return -1;
+    if (prec != PREC_BF16)
+        return conv1_wgrad_f32(g, g_cs, code, c_cs, data, data_cs, sidx, sidx_cs, dw, dw_cs, db, db_cs, scratch,
+                               scratch_floats, K, B, F, KS, opt, stream);
+    if (K <= 0 || B <= 0 || F <= 0 || F > 32) return -1;
+    // float4 / word loads of the pooled gradient and the codes of an image
+    if (((uintptr_t)g & 15) || (g_cs & 3) || ((uintptr_t)code & 3) || (c_cs & 3)) return -2;
+    const int splits = conv1_wgrad_splits(K, B);
+    if (scratch == nullptr || scratch_floats < (long)K * splits * 4 * 2 * 1024) return -5;
+    Conv1WgradArgs a{g, g_cs, code, c_cs, data, data_cs, sidx, sidx_cs, dw, dw_cs, db, db_cs, B, F, scratch};
     dim3 grid(splits, 1, K);
     if (KS == 5) hipLaunchKernelGGL(conv1_wgrad_kernel<5>, grid, dim3(256), 0, stream, a);
     else if (KS == 7) hipLaunchKernelGGL(conv1_wgrad_kernel<7>, grid, dim3(256), 0, stream, a);
     else return -3;
-    P2PFL_RETURN_LAST_ERROR();
+    return conv1_wgrad_finish(scratch, splits * 4, 2, /*tap8=*/1, dw, dw_cs, db, db_cs, K, F, KS, opt, stream);
 }

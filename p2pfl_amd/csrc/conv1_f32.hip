@@ -178,9 +178,10 @@ struct Conv1WgradArgs {
     const uint8_t* code; long c_cs;
     const float* data; long data_cs;
     const int* sidx;   long sidx_cs;
-    float* dw;         long dw_cs;     // [K][F][KS*KS]  (must be zeroed)
-    float* db;         long db_cs;     // [K][F]         (must be zeroed)
+    float* dw;         long dw_cs;     // [K][F][KS*KS]  (written by the finishing pass, unless it applies the optimizer)
+    float* db;         long db_cs;     // [K][F]
     int B, F;
+    float* part;                       // per-wave partial tiles [K][gridDim.x * 4][NJN][16][64] (raw accumulator layout)
 };
 
 constexpr int WG_ROWS = 36;     // last row 2*13 + 1 + tap row 6 = 33
@@ -310,20 +311,13 @@ __global__ __launch_bounds__(256) void conv1_wgrad_f32_kernel(Conv1WgradArgs a) 
         __syncthreads();
         cur ^= 1;
     }
-    // acc[jn][e] = partial dW[f = mfma_row(e)][column n = jn*32 + r] of this wave's window rows
-    float* dw = a.dw + c * a.dw_cs;
-    float* db = a.db + c * a.db_cs;
+    // acc[jn][e] = partial dW[f = mfma_row(e)][column n = jn*32 + r] of this wave's window rows: stored raw (coalesced,
+    // no atomics); conv1_wgrad_finish_kernel adds the partials of a client up in a fixed order - bitwise reproducible
+    float* pw = a.part + (((size_t)c * gridDim.x + blockIdx.x) * 4 + wave) * (NJN * 1024);
 #pragma unroll
-    for (int jn = 0; jn < NJN; ++jn) {
-        const int n = jn * 32 + r;
+    for (int jn = 0; jn < NJN; ++jn)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int fo = mfma_row(e, lane);
-            if (fo >= a.F) continue;
-            if (n == T) atomicAdd(db + fo, acc[jn][e]);
-            else if (n < T) atomicAdd(dw + fo * T + n, acc[jn][e]);
-        }
-    }
+        for (int e = 0; e < 16; ++e) pw[(jn * 16 + e) * 64 + lane] = acc[jn][e];
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -348,19 +342,25 @@ int conv1_fwd_f32(const float* data, long data_cs, const int* sidx, long sidx_cs
 }
 
 int conv1_wgrad_f32(const float* g, long g_cs, const uint8_t* code, long c_cs, const float* data, long data_cs,
-                    const int* sidx, long sidx_cs, float* dw, long dw_cs, float* db, long db_cs, int K, int B, int F,
-                    int KS, hipStream_t stream) {
+                    const int* sidx, long sidx_cs, float* dw, long dw_cs, float* db, long db_cs, float* scratch,
+                    long scratch_floats, int K, int B, int F, int KS, const P2pflOpt* opt, hipStream_t stream) {
     if (K <= 0 || B <= 0 || F <= 0 || F > 32) return -1;
-    // dw/db are accumulated with atomics: the caller zeroes them first (p2pfl_zero_rows).
     if (((uintptr_t)g & 15) || (g_cs & 3) || ((uintptr_t)code & 3) || (c_cs & 3)) return -2;
-    // matrix-pipe-bound: about two blocks per CU over the launch, at most one per image
-    int splits = cdiv(512, K);
-    if (splits > B) splits = B;
-    if (splits < 1) splits = 1;
-    Conv1WgradArgs a{g, g_cs, code, c_cs, data, data_cs, sidx, sidx_cs, dw, dw_cs, db, db_cs, B, F};
+    const int splits = conv1_wgrad_f32_splits(K, B);
+    const int njn = (KS * KS + 1 + 31) / 32;
+    if (scratch == nullptr || scratch_floats < (long)K * splits * 4 * njn * 1024) return -5;
+    Conv1WgradArgs a{g, g_cs, code, c_cs, data, data_cs, sidx, sidx_cs, dw, dw_cs, db, db_cs, B, F, scratch};
     dim3 grid(splits, 1, K);
     if (KS == 5) hipLaunchKernelGGL(conv1_wgrad_f32_kernel<5>, grid, dim3(256), 0, stream, a);
     else if (KS == 7) hipLaunchKernelGGL(conv1_wgrad_f32_kernel<7>, grid, dim3(256), 0, stream, a);
     else return -3;
-    P2PFL_RETURN_LAST_ERROR();
+    return conv1_wgrad_finish(scratch, splits * 4, njn, /*tap8=*/0, dw, dw_cs, db, db_cs, K, F, KS, opt, stream);
+}
+
+// blocks per client - matrix-pipe-bound: about two blocks per CU over the launch, at most one per image
+int conv1_wgrad_f32_splits(int K, int B) {
+    int splits = cdiv(512, K);
+    if (splits > B) splits = B;
+    if (splits < 1) splits = 1;
+    return splits;
 }

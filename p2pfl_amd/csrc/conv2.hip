@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "conv_f32.h"
+#include "opt_epi.h"
 
 namespace {
 
@@ -557,7 +558,8 @@ struct WgradArgs {
     float* dw;         long dw_cs;     // [K][64][32*T]
     float* db;         long db_cs;     // [K][64]
     int K, B;
-    float* part;       int NS;         // NS > 1: batch split, partials [K][NS][T*64*32 + 64] (see reduce kernel)
+    float* part;       int NS;         // part != null: batch split, partials [K][NS][T*64*32 + 64] (see reduce kernel)
+    OptEpi opt;                        // optimizer applied by the reduce kernel (kind 0: it writes dw / db)
 };
 
 template <int KS, int NP>
@@ -688,7 +690,7 @@ __global__ __launch_bounds__(512, 2) void conv2_wgrad_kernel(WgradArgs a) {
     }
 
     const int ci = lane & 31;
-    if (a.NS > 1) {
+    if (a.part != nullptr) {
         // partial of this batch split, tap-major [t][n][ci] (a store instruction covers two 128-B runs; the
         // dW layout costs 64 scattered dwords per instruction: 80 vs 57 us for 10 clients), then the bias
         float* pw = a.part + ((size_t)c * a.NS + split) * (T * COUT * CIN + COUT);
@@ -878,7 +880,7 @@ __global__ __launch_bounds__(512, 1) void conv2_wgrad_split_kernel(WgradArgs a) 
     }
 
     const int ci = lane & 31;
-    if (a.NS > 1) {
+    if (a.part != nullptr) {
         float* pw = a.part + ((size_t)c * a.NS + split) * (T * COUT * CIN + COUT);
 #pragma unroll
         for (int j = 0; j < NTAP; ++j) {
@@ -926,12 +928,18 @@ __global__ __launch_bounds__(256) void conv2_wgrad_reduce_kernel(WgradArgs a) {
         for (int k = 0; k < a.NS; ++k) s += p[(size_t)k * PW + (t * COUT + n) * CIN + ci];
         tr[ci * T + t] = s;
     }
+    const OptEpi::Scal sc = a.opt.kind ? a.opt.scal() : OptEpi::Scal{0.f, 0.f};
     if (threadIdx.x == 0) {
         float s = 0.f;
         for (int k = 0; k < a.NS; ++k) s += p[(size_t)k * PW + NW + n];
-        a.db[c * a.db_cs + n] = s;
+        if (a.opt.kind) a.opt.bias(sc, c, n, s);
+        else a.db[c * a.db_cs + n] = s;
     }
     __syncthreads();
+    if (a.opt.kind) {      // the final gradient is in hand: update filter n in place, the gradient never reaches memory
+        for (int i = threadIdx.x; i < CIN * T; i += 256) a.opt.weight(sc, c, (long)n * CIN * T + i, tr[i]);
+        return;
+    }
     float* dw = a.dw + c * a.dw_cs + (size_t)n * CIN * T;
     for (int i = threadIdx.x; i < CIN * T; i += 256) dw[i] = tr[i];
 }
@@ -1019,7 +1027,7 @@ static void launch_wgrad(const WgradArgs& a, int np, hipStream_t stream) {
     if (np == 1) hipLaunchKernelGGL((conv2_wgrad_kernel<KS, 1>), dim3(slots), block, 0, stream, a);
     else if (np == 2) hipLaunchKernelGGL((conv2_wgrad_kernel<KS, 2>), dim3(slots * 2), block, 0, stream, a);
     else hipLaunchKernelGGL((conv2_wgrad_kernel<KS, 5>), dim3(slots * 5), block, 0, stream, a);
-    if (a.NS > 1)
+    if (a.part != nullptr)
         hipLaunchKernelGGL(conv2_wgrad_reduce_kernel<KS>, dim3(COUT, a.K), dim3(256), 0, stream, a);
 }
 
@@ -1070,23 +1078,31 @@ P2PFL_API long p2pfl_conv2_wgrad_scratch(int K, int B, int KS, int prec) {
     return ns > 1 ? (long)K * ns * (KS * KS * COUT * CIN + COUT) : 0;
 }
 
-P2PFL_API int p2pfl_conv2_wgrad(const float* g, long g_cs, const uint8_t* code, long c_cs, const float* a1,
-                                long a1_cs, float* dw, long dw_cs, float* db, long db_cs, float* scratch,
-                                long scratch_floats, int K, int B, int CIN_, int COUT_, int KS, int prec,
-                                int flags, hipStream_t stream) {
+// ``opt`` (optional): the optimizer step of this layer runs in the reduction pass that holds the final gradient - dw / db
+// are then NOT written (may be null) and the partial-sum path is taken even for one batch split, so ``scratch`` must
+// hold K * max(ns, 1) * (KS*KS*64*32 + 64) floats (-5 otherwise).
+P2PFL_API int p2pfl_conv2_wgrad_opt(const float* g, long g_cs, const uint8_t* code, long c_cs, const float* a1,
+                                    long a1_cs, float* dw, long dw_cs, float* db, long db_cs, float* scratch,
+                                    long scratch_floats, int K, int B, int CIN_, int COUT_, int KS, int prec,
+                                    int flags, const P2pflOpt* opt, hipStream_t stream) {
     if (K <= 0 || B <= 0 || CIN_ != CIN || COUT_ != COUT) return -1;
+    if (!opt_epi_valid(opt)) return -1;
+    const bool fold = opt != nullptr && opt->kind != 0;
     if (prec == PREC_F32)
         return conv2_wgrad_f32(g, g_cs, code, c_cs, a1, a1_cs, dw, dw_cs, db, db_cs, scratch, scratch_floats, K, B, KS,
-                               flags, stream);
+                               flags, opt, stream);
     if (KS != 5 && KS != 3) return -3;
+    const long pw = (long)KS * KS * COUT * CIN + COUT;
     if (prec == PREC_F32_SPLIT) {
         int ns = wgrad_split_batches(K, B, num_cus());
-        if (scratch == nullptr || scratch_floats < (long)K * ns * (KS * KS * COUT * CIN + COUT)) ns = 1;
-        WgradArgs a{g, g_cs, code, c_cs, a1, a1_cs, dw, dw_cs, db, db_cs, K, B, scratch, ns};
+        if (scratch == nullptr || scratch_floats < (long)K * ns * pw) ns = 1;
+        if (fold && (scratch == nullptr || scratch_floats < (long)K * ns * pw)) return -5;
+        WgradArgs a{g, g_cs, code, c_cs, a1, a1_cs, dw, dw_cs, db, db_cs, K, B, (ns > 1 || fold) ? scratch : nullptr, ns,
+                    make_opt_epi(opt)};
         const dim3 grid(cdiv(K, 8) * 8 * 2 * ns);
         if (KS == 5) hipLaunchKernelGGL((conv2_wgrad_split_kernel<5, SPLIT_TERMS>), grid, dim3(512), 0, stream, a);
         else hipLaunchKernelGGL((conv2_wgrad_split_kernel<3, SPLIT_TERMS>), grid, dim3(512), 0, stream, a);
-        if (ns > 1) {
+        if (a.part != nullptr) {
             if (KS == 5) hipLaunchKernelGGL(conv2_wgrad_reduce_kernel<5>, dim3(COUT, K), dim3(256), 0, stream, a);
             else hipLaunchKernelGGL(conv2_wgrad_reduce_kernel<3>, dim3(COUT, K), dim3(256), 0, stream, a);
         }
@@ -1094,9 +1110,19 @@ P2PFL_API int p2pfl_conv2_wgrad(const float* g, long g_cs, const uint8_t* code, 
     }
     int np, ns;
     wgrad_split(K, B, KS, num_cus(), np, ns);
-    if (scratch == nullptr || scratch_floats < (long)K * ns * (KS * KS * COUT * CIN + COUT)) ns = 1;
-    WgradArgs a{g, g_cs, code, c_cs, a1, a1_cs, dw, dw_cs, db, db_cs, K, B, scratch, ns};
+    if (scratch == nullptr || scratch_floats < (long)K * ns * pw) ns = 1;
+    if (fold && (scratch == nullptr || scratch_floats < (long)K * ns * pw)) return -5;
+    WgradArgs a{g, g_cs, code, c_cs, a1, a1_cs, dw, dw_cs, db, db_cs, K, B, (ns > 1 || fold) ? scratch : nullptr, ns,
+                make_opt_epi(opt)};
     if (KS == 5) launch_wgrad<5>(a, np, stream);
     else launch_wgrad<3>(a, np, stream);
     P2PFL_RETURN_LAST_ERROR();
+}
+
+P2PFL_API int p2pfl_conv2_wgrad(const float* g, long g_cs, const uint8_t* code, long c_cs, const float* a1,
+                                long a1_cs, float* dw, long dw_cs, float* db, long db_cs, float* scratch,
+                                long scratch_floats, int K, int B, int CIN_, int COUT_, int KS, int prec,
+                                int flags, hipStream_t stream) {
+    return p2pfl_conv2_wgrad_opt(g, g_cs, code, c_cs, a1, a1_cs, dw, dw_cs, db, db_cs, scratch, scratch_floats, K, B,
+                                 CIN_, COUT_, KS, prec, flags, nullptr, stream);
 }

@@ -26,6 +26,7 @@
 // Reference layers: fedstellar/learning/pytorch/mnist/models/cnn.py:138-142,152-154 and
 // fedstellar/learning/pytorch/femnist/models/cnn.py:137-139,147-148.
 #include "conv_f32.h"
+#include "opt_epi.h"
 
 #include <map>
 #include <mutex>
@@ -358,7 +359,8 @@ struct WgradArgs {
     float* dw;         long dw_cs;     // [K][64][32*T]
     float* db;         long db_cs;     // [K][64]
     int K, B;
-    float* part;       int NS;         // NS > 1: batch split, partials [K][NS][T*64*32 + 64]
+    float* part;       int NS;         // part != null: batch split, partials [K][NS][T*64*32 + 64]
+    OptEpi opt;                        // optimizer applied by the reduce kernel (kind 0: it writes dw / db)
 };
 
 // MH = output channels per block: 64 (8 waves = 4 tap groups x 2 row tiles, 92 KB of LDS) or 32 (4 waves = 4 tap
@@ -513,7 +515,7 @@ __device__ __forceinline__ void conv2_wgrad_f32_body(const WgradArgs& a) {
 
     const int ci = r;
     bsum += __shfl_xor(bsum, 32, 64);      // both pixel parities
-    if (a.NS > 1) {
+    if (a.part != nullptr) {
         // partial of this batch split, tap-major [t][n][ci], then the bias
         float* pw = a.part + ((size_t)c * a.NS + split) * (T * COUT * CIN + COUT);
 #pragma unroll
@@ -572,12 +574,18 @@ __global__ __launch_bounds__(256) void conv2_wgrad_reduce_f32_kernel(WgradArgs a
         for (int k = 0; k < a.NS; ++k) s += p[(size_t)k * PW + (t * COUT + n) * CIN + ci];
         tr[ci * T + t] = s;
     }
+    const OptEpi::Scal sc = a.opt.kind ? a.opt.scal() : OptEpi::Scal{0.f, 0.f};
     if (threadIdx.x == 0) {
         float s = 0.f;
         for (int k = 0; k < a.NS; ++k) s += p[(size_t)k * PW + NW + n];
-        a.db[c * a.db_cs + n] = s;
+        if (a.opt.kind) a.opt.bias(sc, c, n, s);
+        else a.db[c * a.db_cs + n] = s;
     }
     __syncthreads();
+    if (a.opt.kind) {      // the final gradient is in hand: update filter n in place, the gradient never reaches memory
+        for (int i = threadIdx.x; i < CIN * T; i += 256) a.opt.weight(sc, c, (long)n * CIN * T + i, tr[i]);
+        return;
+    }
     float* dw = a.dw + c * a.dw_cs + (size_t)n * CIN * T;
     for (int i = threadIdx.x; i < CIN * T; i += 256) dw[i] = tr[i];
 }
@@ -667,7 +675,7 @@ void launch_wgrad(const WgradArgs& a, int np, bool small, hipStream_t stream) {
         else if (np == 2) hipLaunchKernelGGL((conv2_wgrad_f32_kernel<KS, 2>), dim3(slots * 2), block, 0, stream, a);
         else hipLaunchKernelGGL((conv2_wgrad_f32_kernel<KS, 5>), dim3(slots * 5), block, 0, stream, a);
     }
-    if (a.NS > 1)
+    if (a.part != nullptr)
         hipLaunchKernelGGL(conv2_wgrad_reduce_f32_kernel<KS>, dim3(COUT, a.K), dim3(256), 0, stream, a);
 }
 
@@ -729,14 +737,18 @@ long conv2_wgrad_f32_scratch(int K, int B, int KS) {      // (enough for either 
 
 int conv2_wgrad_f32(const float* g, long g_cs, const uint8_t* code, long c_cs, const float* a1, long a1_cs, float* dw,
                     long dw_cs, float* db, long db_cs, float* scratch, long scratch_floats, int K, int B, int KS,
-                    int flags, hipStream_t stream) {
+                    int flags, const P2pflOpt* opt, hipStream_t stream) {
     if (K <= 0 || B <= 0) return -1;
     if (((uintptr_t)a1 & 15) || (a1_cs & 3)) return -2;
     const bool small = want_small(flags);
+    const bool fold = opt != nullptr && opt->kind != 0;
     int np, ns;
     wgrad_split_f32(K, B, KS, num_cus(), small, np, ns);
-    if (scratch == nullptr || scratch_floats < (long)K * ns * (KS * KS * COUT * CIN + COUT)) ns = 1;
-    WgradArgs a{g, g_cs, code, c_cs, a1, a1_cs, dw, dw_cs, db, db_cs, K, B, scratch, ns};
+    const long pw = (long)KS * KS * COUT * CIN + COUT;
+    if (scratch == nullptr || scratch_floats < (long)K * ns * pw) ns = 1;
+    if (fold && (scratch == nullptr || scratch_floats < (long)K * ns * pw)) return -5;
+    WgradArgs a{g, g_cs, code, c_cs, a1, a1_cs, dw, dw_cs, db, db_cs, K, B, (ns > 1 || fold) ? scratch : nullptr, ns,
+                make_opt_epi(opt)};
     if (KS == 5) launch_wgrad<5>(a, np, small, stream);
     else if (KS == 3) launch_wgrad<3>(a, np, small, stream);
     else return -3;

@@ -76,8 +76,9 @@ def default_precision() -> str:
 
 _PRODUCT_OPS = frozenset((
     "linear_fwd", "linear_dgrad", "linear_wgrad", "linear_wgrad_adam", "linear_wgrad_adam_dgrad", "linear_wgrad_sgdm",
-    "conv1_fwd", "conv1_wgrad",
-    "conv2_prep_alloc", "conv2_prep", "conv2_fwd", "conv2_wgrad_scratch", "conv2_wgrad", "conv2_dgrad"))
+    "conv1_fwd", "conv1_wgrad", "conv1_wgrad_scratch",
+    "conv2_prep_alloc", "conv2_prep", "conv2_fwd", "conv2_wgrad_scratch", "conv2_wgrad_scratch_opt", "conv2_wgrad",
+    "conv2_dgrad"))
 
 
 class _Bound:
@@ -122,7 +123,11 @@ class _Sig:
     p2pfl_linear_wgrad_adam_dgrad = [P, L, P, L, P, P, P, L, P, P, P, L, P, L, I, I, I, I, F, F, F, F, F, I, P, I, P, L, I, P]
     p2pfl_linear_wgrad_sgdm = [P, L, P, L, P, P, L, P, P, L, I, I, I, I, F, F, F, I, P, L, I, P]
     p2pfl_conv1_fwd = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, P]
-    p2pfl_conv1_wgrad = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, P]
+    p2pfl_conv1_wgrad = [P, L, P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, P, P]
+    p2pfl_conv1_wgrad_scratch = [I, I, I, I]
+    p2pfl_conv2_wgrad_opt = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, I, I, P, P]
+    p2pfl_linear_head = [P, L, P, L, P, L, P, L, P, L, P, L, P, L, P, L, P, L, P, P, P, P, P, L, I, I, I, I, I, P, P]
+    p2pfl_linear_head_accepts = [I, I, I]
     p2pfl_conv2_prep = [P, L, P, L, I, I, I, I, I, P]
     p2pfl_conv2_fwd = [P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, I, I, P]
     p2pfl_conv2_wgrad = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, I, I, P]
@@ -137,6 +142,37 @@ class _Sig:
     p2pfl_fedavg_inplace = [P, L, I, P, L, I, P, P, P, P, P, I, L, P]
     p2pfl_fedavg_inplace_chunk = [I]
     p2pfl_aes128_ecb = [P, P, P, L, I, P]
+
+
+class OptStruct(ctypes.Structure):
+    """``P2pflOpt`` of csrc/opt_epi.h: the optimizer step a gradient-producing kernel applies in its epilogue."""
+    _fields_ = [("kind", c_int), ("t", c_int),
+                ("pw", c_void_p), ("mw", c_void_p), ("vw", c_void_p),
+                ("pb", c_void_p), ("mb", c_void_p), ("vb", c_void_p),
+                ("cs", c_long),
+                ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
+                ("weight_decay", c_float), ("momentum", c_float),
+                ("bc", c_void_p)]
+
+
+def fold_opt(kind: str, w, mw, vw, b, mb, vb, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, momentum=0.9,
+             t: int = 1, bc=None) -> OptStruct:
+    """Optimizer epilogue for one layer: ``w/mw/vw`` [K,...] and ``b/mb/vb`` [K,Out] are views of the parameter /
+    moment slabs (``vw``/``vb`` None for SGD-momentum) that share ONE row stride. ``kind``: "adam" | "sgd"."""
+    cs = w.stride(0)
+    views = [w, mw, b, mb] + ([vw, vb] if kind == "adam" else [])
+    for v in views:
+        _t(v)
+        if v.shape[0] > 1 and v.stride(0) != cs:        # (one client: the stride of a size-1 dimension means nothing)
+            raise HipKernelError("optimizer epilogue: all parameter / moment views must share one row stride")
+    ptr = lambda v: None if v is None else v.data_ptr()
+    return OptStruct(1 if kind == "adam" else 2, int(t), ptr(w), ptr(mw), ptr(vw) if kind == "adam" else None,
+                     ptr(b), ptr(mb), ptr(vb) if kind == "adam" else None, cs, lr, beta1, beta2, eps, weight_decay,
+                     momentum, None if bc is None else _t(bc).data_ptr())
+
+
+def _optp(opt):
+    return None if opt is None else ctypes.byref(opt)
 
 
 def _stream() -> int:
@@ -298,15 +334,34 @@ def conv1_fwd(data, sidx, w, bias, a1, code, ks: int, prec=None) -> None:
          "conv1_fwd")
 
 
-def conv1_wgrad(g, code, data, sidx, dw, db, ks: int, prec=None) -> None:
-    """Stage-1 weight/bias gradient (dw/db are zeroed here, then accumulated with atomics)."""
+_c1_scratch = {}
+
+
+def conv1_wgrad_scratch(K: int, B: int, ks: int, device, prec=None) -> torch.Tensor:
+    """Scratch buffer of :func:`conv1_wgrad` (per-wave partial tiles) for this problem size."""
+    need = int(load().p2pfl_conv1_wgrad_scratch(K, B, ks, _prec(prec)))
+    return torch.empty(max(need, 1), dtype=torch.float32, device=device)
+
+
+def conv1_wgrad(g, code, data, sidx, dw, db, ks: int, scratch: Optional[torch.Tensor] = None, opt: Optional[OptStruct] = None,
+                prec=None) -> None:
+    """Stage-1 weight / bias gradient: per-wave partial tiles go through ``scratch`` and a finishing pass adds them up
+    in a fixed order (no atomics: bitwise reproducible), then stores dw / db - or, with ``opt`` (:func:`fold_opt`),
+    applies the layer's optimizer step instead (dw / db may then be None)."""
     K, B, Fm = g.shape[0], g.shape[1], g.shape[2]
-    zero_rows(dw)
-    zero_rows(db)
     (gp, gs), (dp, ds), (sp, ss), (wp, ws), (bp, bs) = _pc(g), _pc(data), _pc(sidx, torch.int32), _pc(dw), _pc(db)
     cp, cs = _pc(code, torch.uint8)
-    _chk(load().p2pfl_conv1_wgrad(gp, gs, cp, cs, dp, ds, sp, ss, wp, ws, bp, bs, K, B, Fm, ks, _prec(prec),
-                                  _stream()), "conv1_wgrad")
+    lib = load()
+    need = int(lib.p2pfl_conv1_wgrad_scratch(K, B, ks, _prec(prec)))
+    if scratch is not None and scratch.numel() >= need:
+        buf = _t(scratch)
+    else:
+        key = (g.device, int(_stream() or 0), threading.get_ident())
+        buf = _c1_scratch.get(key)
+        if buf is None or buf.numel() < need:
+            buf = _c1_scratch[key] = torch.empty(need, dtype=torch.float32, device=g.device)
+    _chk(lib.p2pfl_conv1_wgrad(gp, gs, cp, cs, dp, ds, sp, ss, wp, ws, bp, bs, buf.data_ptr(), buf.numel(), K, B, Fm, ks,
+                               _prec(prec), _optp(opt), _stream()), "conv1_wgrad")
 
 
 def _prep_dtype(prec):
@@ -360,9 +415,16 @@ def conv2_wgrad_scratch(K: int, B: int, ks: int, device, prec=None) -> Optional[
     return torch.empty(need, dtype=torch.float32, device=device) if need else None
 
 
+def conv2_wgrad_scratch_opt(K: int, B: int, ks: int, device, prec=None) -> torch.Tensor:
+    """Scratch of :func:`conv2_wgrad` with an optimizer epilogue: the partial-sum pass is then always taken."""
+    need = max(int(load().p2pfl_conv2_wgrad_scratch(K, B, ks, _prec(prec))), K * (ks * ks * 64 * 32 + 64))
+    return torch.empty(need, dtype=torch.float32, device=device)
+
+
 def conv2_wgrad(g, code, a1, dw, db, ks: int, scratch: Optional[torch.Tensor] = None, prec=None,
-                coresident: bool = False) -> None:
-    """Stage-2 weight/bias gradient: dw [K,Cout,Cin*ks*ks], db [K,Cout] (overwritten).
+                coresident: bool = False, opt: Optional[OptStruct] = None) -> None:
+    """Stage-2 weight/bias gradient: dw [K,Cout,Cin*ks*ks], db [K,Cout] (overwritten) - or, with ``opt``
+    (:func:`fold_opt`), the layer's optimizer step applied by the reduction pass (dw / db may then be None).
 
     ``scratch``: buffer from :func:`conv2_wgrad_scratch` owned by the caller (one call in flight per buffer);
     without it a module-level buffer per (device, stream, thread) is used."""
@@ -373,6 +435,8 @@ def conv2_wgrad(g, code, a1, dw, db, ks: int, scratch: Optional[torch.Tensor] = 
     lib = load()
     stream = _stream()
     need = int(lib.p2pfl_conv2_wgrad_scratch(K, B, ks, _prec(prec)))
+    if opt is not None:
+        need = max(need, K * (ks * ks * Cout * Cin + Cout))
     sp = 0
     if need:
         if scratch is not None and scratch.numel() >= need:
@@ -383,8 +447,9 @@ def conv2_wgrad(g, code, a1, dw, db, ks: int, scratch: Optional[torch.Tensor] = 
             if buf is None or buf.numel() < need:
                 buf = _wgrad_scratch[key] = torch.empty(need, dtype=torch.float32, device=g.device)
         sp = buf.data_ptr()
-    _chk(lib.p2pfl_conv2_wgrad(gp, gs, cp, cs, ap, as_, wp, ws, bp, bs, sp, need, K, B, Cin, Cout, ks, _prec(prec),
-                               int(coresident), stream), "conv2_wgrad")
+        need = buf.numel()
+    _chk(lib.p2pfl_conv2_wgrad_opt(gp, gs, cp, cs, ap, as_, wp, ws, bp, bs, sp, need, K, B, Cin, Cout, ks, _prec(prec),
+                                   int(coresident), _optp(opt), stream), "conv2_wgrad")
 
 
 def conv2_dgrad(g, code, w, da1, ks: int, wprep=None, prec=None, coresident: bool = False) -> None:
@@ -409,6 +474,30 @@ def softmax_ce(logits, labels, sidx, dlogits, loss_sum, correct, count, confusio
                                  _t(correct, torch.int32).data_ptr(), _t(count, torch.int32).data_ptr(),
                                  None if confusion is None else _t(confusion, torch.int32).data_ptr(),
                                  nvp, nvs, K, B, C, _stream()), "softmax_ce")
+
+
+def linear_head_accepts(B: int, In: int, C: int) -> bool:
+    return bool(load().p2pfl_linear_head_accepts(B, In, C))
+
+
+def linear_head(x, w, b, labels, sidx, loss_sum, correct, count, confusion=None, n_valid=None, *, dx=None, dw=None,
+                db=None, logits=None, relu_mask: bool = False, opt: Optional[OptStruct] = None) -> None:
+    """The classification head of a training step in one kernel per client (csrc/head.hip): logits = x w^T + b,
+    softmax cross-entropy + metric counters, ``dx = (dlogits w) * [x > 0 if relu_mask]``, and either the gradients
+    ``dw`` / ``db`` or - with ``opt`` (:func:`fold_opt` over these very ``w`` / ``b`` views) - the optimizer step in
+    place. x [K,B,In] (B <= 32), w [K,C,In] (C <= 16), b [K,C], labels [K,n] int32, dx [K,B,In] or None."""
+    K, B, In = x.shape
+    C = w.shape[1]
+    assert w.shape == (K, C, In) and b.shape == (K, C)
+    assert dx is None or dx.shape == (K, B, In)
+    (xp, xs), (wp, ws), (bp, bs), (gp, gs) = _pc(x), _pc(w), _pc(b), _pc(dx)
+    (dwp, dws), (dbp, dbs), (lp, ls) = _pc(dw), _pc(db), _pc(logits)
+    (yp, ys), (sp, ss), (nvp, nvs) = _pc(labels, torch.int32), _pc(sidx, torch.int32), _pc(n_valid, torch.int32)
+    _chk(load().p2pfl_linear_head(xp, xs, wp, ws, bp, bs, gp, gs, dwp, dws, dbp, dbs, lp, ls, yp, ys, sp, ss,
+                                  _t(loss_sum).data_ptr(), _t(correct, torch.int32).data_ptr(),
+                                  _t(count, torch.int32).data_ptr(),
+                                  None if confusion is None else _t(confusion, torch.int32).data_ptr(),
+                                  nvp, nvs, K, B, In, C, int(relu_mask), _optp(opt), _stream()), "linear_head")
 
 
 def zero_rows(t) -> None:

@@ -390,6 +390,47 @@ class HipEngine(ShardEngine):
             if pos < L.row_stride:
                 ranges.append((pos, L.row_stride))
             self._adam_ranges = ranges
+        # everything the big fused layers do not own is cleared when a round starts a new optimizer
+        self._zero_ranges = list(self._adam_ranges)
+        # Small layers: the optimizer step runs in the EPILOGUE of the kernel that holds the layer's final gradient
+        # (fixed-order reduction passes of the convolution weight gradients; the one-kernel class head), so their
+        # gradients never reach memory and the element-wise optimizer launches (4 per step, each waiting for wave
+        # slots beside the other group's HBM-bound update: 20 us alone, 270 us in the schedule) are gone.
+        # P2PFL_NO_FOLD=1 keeps the separate launches (A/B runs).
+        self._fold = set()
+        self._head = None
+        last = len(self.spec.layers) - 1
+        ll = self.spec.layers[last]
+        if (ll.kind == "linear" and last > 0 and not ll.relu and last not in self._fused
+                and not os.environ.get("P2PFL_NO_HEAD") and hip.linear_head_accepts(B, ll.in_features, ll.out_features)):
+            self._head = last
+        if o.kind in ("adam", "sgd") and fuse_optimizer and not os.environ.get("P2PFL_NO_FUSE") \
+                and not os.environ.get("P2PFL_NO_FOLD"):
+            for i, l in enumerate(self.spec.layers):
+                if l.kind in ("conv1pool", "conv2pool") or i == self._head:
+                    self._fold.add(i)
+            cut = []
+            for i in sorted(self._fold):
+                l = self.spec.layers[i]
+                for slot in (L.by_name[l.weight], L.by_name[l.bias]):
+                    cut.append((slot.offset, slot.offset + -(-slot.numel // 64) * 64))
+            ranges = []
+            for a, b in self._adam_ranges:
+                pos = a
+                for ca, cb in sorted(cut):
+                    if cb <= pos or ca >= b:
+                        continue
+                    if ca > pos:
+                        ranges.append((pos, ca))
+                    pos = max(pos, cb)
+                if pos < b:
+                    ranges.append((pos, b))
+            self._adam_ranges = ranges
+        self.c1_scratch = {i: hip.conv1_wgrad_scratch(K, B, l.ksize, dev) for i, l in enumerate(self.spec.layers)
+                           if l.kind == "conv1pool"}
+        for i in self.w2_scratch:
+            if i in self._fold:
+                self.w2_scratch[i] = hip.conv2_wgrad_scratch_opt(K, B, self.spec.layers[i].ksize, dev)
         self._graphs: Dict[tuple, tuple] = {}
         self._capturing = False
         self._stream_debug = [] if os.environ.get("P2PFL_STREAM_DEBUG") else None
@@ -477,7 +518,7 @@ class HipEngine(ShardEngine):
     def reset_optimizer(self) -> None:
         # moments of the fused layers are not cleared when every round starts a new optimizer: their first
         # fused step overwrites them without reading (saves two passes over the biggest tensors per round)
-        ranges = self._adam_ranges if (self._fused and not self.persist_optimizer) else [(0, self.layout.row_stride)]
+        ranges = self._zero_ranges if (self._fused and not self.persist_optimizer) else [(0, self.layout.row_stride)]
         for a, b in ranges:
             self.m[:, a:b].zero_()
             if self.v is not None:
@@ -498,6 +539,9 @@ class HipEngine(ShardEngine):
         act, code, B = bufs if bufs is not None else (self.act, self.code, self.B)
         x = None
         for i, l in enumerate(layers):
+            if train and i == self._head:      # forward, loss and backward of the head are one kernel: _backward starts with it
+                self._head_in = (x, labels, sidx, n_valid)
+                return
             W, b = self._w(self.params, l)
             if l.kind == "conv1pool":
                 hip.conv1_fwd(data, sidx, W, b, act[i], code[i], l.ksize)
@@ -548,7 +592,11 @@ class HipEngine(ShardEngine):
             l = layers[i]
             W, _ = self._w(self.params, l)
             gW, gb = self._w(self.grads, l)
-            if l.kind == "linear":
+            if i == self._head:
+                x, labels, lsidx, n_valid = self._head_in
+                self._head_step(x, labels, lsidx, n_valid, step_index)
+                dy = self.dact[i - 1]
+            elif l.kind == "linear":
                 gather = None
                 if i == 0:
                     xin, gather = (data, sidx) if sidx is not None else (data[:, :self.B], None)
@@ -574,11 +622,13 @@ class HipEngine(ShardEngine):
                 if dy_next is not None:
                     dy = dy_next
             elif l.kind == "conv2pool":
-                hip.conv2_wgrad(dy, self.code[i], self.act[i - 1], gW, gb, l.ksize, scratch=self.w2_scratch[i])
+                hip.conv2_wgrad(dy, self.code[i], self.act[i - 1], gW, gb, l.ksize, scratch=self.w2_scratch[i],
+                                opt=self._opt_epilogue(i, step_index))
                 hip.conv2_dgrad(dy, self.code[i], W, self.dact[i - 1], l.ksize, wprep=self.wprep[i])
                 dy = self.dact[i - 1]
             else:  # conv1pool (first layer: no data gradient)
-                hip.conv1_wgrad(dy, self.code[i], data, sidx, gW, gb, l.ksize)
+                hip.conv1_wgrad(dy, self.code[i], data, sidx, gW, gb, l.ksize, scratch=self.c1_scratch[i],
+                                opt=self._opt_epilogue(i, step_index))
 
     def _fused_update(self, l, dy, xin, step_index: int, sidx=None, dx=None) -> bool:
         """Weight gradient of a big linear layer + its optimizer update in one kernel. With ``dx`` the kernel is
@@ -608,8 +658,36 @@ class HipEngine(ShardEngine):
                                        weight_decay=o.weight_decay, fresh=fresh, sidx=sidx)
         return True
 
+    def _opt_epilogue(self, i: int, step_index: int):
+        """Optimizer epilogue (ops/hip.py: fold_opt) of layer ``i`` for step ``step_index``; None: not folded."""
+        if i not in self._fold:
+            return None
+        o, l = self.spec.optim, self.spec.layers[i]
+        (W, b), (Mw, Mb) = self._w(self.params, l), self._w(self.m, l)
+        Vw, Vb = self._w(self.v, l) if o.kind == "adam" else (None, None)
+        return self.hip.fold_opt(o.kind, W, Mw, Vw, b, Mb, Vb, lr=o.lr, beta1=o.beta1, beta2=o.beta2, eps=o.eps,
+                                 weight_decay=o.weight_decay, momentum=o.momentum, t=step_index,
+                                 bc=self._bc_buf[step_index - 1] if self._bc_buf is not None else None)
+
+    def _head_step(self, x, labels, sidx, n_valid, step_index: int) -> None:
+        """Class head of a training step in one kernel (csrc/head.hip): forward, loss + counters, data gradient for
+        the layer below, weight gradient and - folded - the optimizer step of the head."""
+        i = self._head
+        l, prev = self.spec.layers[i], self.spec.layers[i - 1]
+        W, b = self._w(self.params, l)
+        st = self.stats["Train"]
+        opt = self._opt_epilogue(i, step_index)
+        gW, gb = (None, None) if opt is not None else self._w(self.grads, l)
+        dx = self.dact[i - 1].flatten(2) if self.dact[i - 1].dim() > 3 else self.dact[i - 1]
+        self.hip.linear_head(x.flatten(2) if x.dim() > 3 else x, W, b, labels, sidx, st.loss_sum, st.correct, st.count,
+                             st.confusion, n_valid, dx=dx, dw=gW, db=gb,
+                             relu_mask=prev.kind == "linear" and prev.relu, opt=opt)
+        self._record_step()
+
     def _optim_step(self, step_index: int) -> None:
         o = self.spec.optim
+        if not self._adam_ranges:       # every layer's update is fused / folded into its gradient kernel
+            return
         # (one launch over both ranges - hip.adam_step_ranges - is 2.8 ms per headline round SLOWER beside the other
         # group's update than these two: 256.4 vs 253.5 ms, measured twice alternating)
         if o.kind == "adam":
@@ -690,7 +768,7 @@ class HipEngine(ShardEngine):
                 hip.conv2_fwd(x, W, b, out, self.code[i], l.ksize, wprep=self.wprep[i], coresident=coresident)
             x = out
 
-    def _conv_backward(self, data, sidx, coresident: bool = False) -> None:
+    def _conv_backward(self, data, sidx, coresident: bool = False, step_index: int = 1) -> None:
         """Backward pass of the convolution stages. Under the fused update (``coresident``) the kernels that fit on a
         CU beside its two workgroups go first - stage-2 data gradient, stage-1 weight gradient - and the stage-2
         weight gradient (512 threads, 104 KB of LDS in the exact-split policy: it waits for whole free CUs) last, so
@@ -705,7 +783,8 @@ class HipEngine(ShardEngine):
             if l.kind == "conv2pool":
                 def wgrad(i=i, l=l, gW=gW, gb=gb):
                     hip.conv2_wgrad(self.dact[i], self.code[i], self.act[i - 1], gW, gb, l.ksize,
-                                    scratch=self.w2_scratch[i], coresident=coresident)
+                                    scratch=self.w2_scratch[i], coresident=coresident,
+                                    opt=self._opt_epilogue(i, step_index))
                 if i == self.nc - 1 and getattr(self, "_wgrad_ev", None) is not None:
                     ev = self._wgrad_ev                       # ran on the launch stream (see _dense_step)
                     deferred.append(lambda ev=ev: torch.cuda.current_stream().wait_event(ev))
@@ -716,7 +795,8 @@ class HipEngine(ShardEngine):
                 hip.conv2_dgrad(self.dact[i], self.code[i], W, self.dact[i - 1], l.ksize, wprep=self.wprep[i],
                                 coresident=coresident)
             else:
-                hip.conv1_wgrad(self.dact[i], self.code[i], data, sidx, gW, gb, l.ksize)
+                hip.conv1_wgrad(self.dact[i], self.code[i], data, sidx, gW, gb, l.ksize, scratch=self.c1_scratch[i],
+                                opt=self._opt_epilogue(i, step_index))
         for fn in deferred:
             fn()
 
@@ -728,14 +808,20 @@ class HipEngine(ShardEngine):
         hip, layers, nc, o = self.hip, self.spec.layers, self.nc, self.spec.optim
         main = torch.cuda.current_stream()
         x = conv_out.flatten(2)
+        head = self._head if (self._head is not None and self._head > nc) else None
         for i in range(nc, len(layers)):
+            if i == head:
+                break
             W, b = self._w(self.params, layers[i])
             self._linear_fwd(x, W, b, self.act[i], layers[i].relu)
             x = self.act[i]
-        st = self.stats["Train"]
-        hip.softmax_ce(x, labels, sidx, self.dact[-1], st.loss_sum, st.correct, st.count, st.confusion, n_valid)
-        self._record_step()
-        for i in range(len(layers) - 1, nc - 1, -1):
+        if head is not None:
+            self._head_step(x, labels, sidx, n_valid, step_index)
+        else:
+            st = self.stats["Train"]
+            hip.softmax_ce(x, labels, sidx, self.dact[-1], st.loss_sum, st.correct, st.count, st.confusion, n_valid)
+            self._record_step()
+        for i in range(len(layers) - 1 if head is None else head - 1, nc - 1, -1):
             l = layers[i]
             W, _ = self._w(self.params, l)
             xin = conv_out.flatten(2) if i == nc else self.act[i - 1]
@@ -758,7 +844,7 @@ class HipEngine(ShardEngine):
                     lj = layers[j]
                     gWj, gbj = self._w(self.grads, lj)
                     hip.conv2_wgrad(self.dact[j], self.code[j], self.act[j - 1], gWj, gbj, lj.ksize,
-                                    scratch=self.w2_scratch[j])
+                                    scratch=self.w2_scratch[j], opt=self._opt_epilogue(j, step_index))
                     self._wgrad_ev = torch.cuda.Event()
                     self._wgrad_ev.record(main)
             if took:
@@ -806,7 +892,7 @@ class HipEngine(ShardEngine):
                 self._dense_step(self._act_pp[(t - 1) & 1], self.train_y, sidx, nv, t, side)
                 mark(main, f"step {t}: main after fused update")
                 with torch.cuda.stream(side):     # under the fused update: kernel variants that fit beside it on a CU
-                    self._conv_backward(self.train_x, sidx, coresident=True)
+                    self._conv_backward(self.train_x, sidx, coresident=True, step_index=t)
                     self._optim_step(t)
                     if s + 1 < steps:
                         self._conv_forward(self.train_x, self._perm_buf[e, :, (s + 1) * self.B:(s + 2) * self.B],
@@ -843,11 +929,14 @@ class HipEngine(ShardEngine):
                        for ph, st in self.stats.items()}
             v._step_log = None if self._step_log is None else self._step_log[:, :, sl]
             # buffers with static addresses of their own (baked into the captured graph): kept on the engine
-            own = keep.setdefault((G, g), {"nv": {}, "fwd": {}, "w2": None})
+            own = keep.setdefault((G, g), {"nv": {}, "fwd": {}, "w2": None, "c1": None})
             if own["w2"] is None:
-                own["w2"] = {i: self.hip.conv2_wgrad_scratch(v.K, self.B, l.ksize, self.device)
+                own["w2"] = {i: (self.hip.conv2_wgrad_scratch_opt if i in self._fold else self.hip.conv2_wgrad_scratch)(
+                                 v.K, self.B, l.ksize, self.device)
                              for i, l in enumerate(self.spec.layers) if l.kind == "conv2pool"}
-            v._nv_cache, v._fwd_scratch, v.w2_scratch = own["nv"], own["fwd"], own["w2"]
+                own["c1"] = {i: self.hip.conv1_wgrad_scratch(v.K, self.B, l.ksize, self.device)
+                             for i, l in enumerate(self.spec.layers) if l.kind == "conv1pool"}
+            v._nv_cache, v._fwd_scratch, v.w2_scratch, v.c1_scratch = own["nv"], own["fwd"], own["w2"], own["c1"]
             v._wgrad_ev = None
             views.append(v)
         return views
@@ -890,7 +979,7 @@ class HipEngine(ShardEngine):
                     main.wait_event(done[g])
                     v._dense_step(v._act_pp[(t - 1) & 1], v.train_y, sidx, nv, t, side)     # releases side after the update
                     with torch.cuda.stream(side):
-                        v._conv_backward(v.train_x, sidx, coresident=cores)
+                        v._conv_backward(v.train_x, sidx, coresident=cores, step_index=t)
                         v._optim_step(t)
                         if s + 1 < steps:
                             v._conv_forward(v.train_x, self._perm_buf[e, v._rows, (s + 1) * B:(s + 2) * B], v._act_pp[t & 1],
@@ -958,9 +1047,12 @@ class HipEngine(ShardEngine):
                 # warm-up on a side stream (lazy module loads, allocator), then capture
                 # (a fresh stream per capture: with one long-lived warm-up stream the parallel branch of the
                 # captured graph ended up on the hardware queue of the launch stream - headline 237 -> 259 ms)
+                # (the snapshot BEFORE the warm-up stream picks up its dependency on this one: taken after
+                # `s.wait_stream`, the clones raced the warm-up - the class head, whose update is the first thing a step
+                # writes, saw second moments that already contained the warm-up's gradients)
+                snap = (self.params.clone(), self.m.clone(), None if self.v is None else self.v.clone())
                 s = torch.cuda.Stream(device=self.device)
                 s.wait_stream(torch.cuda.current_stream())
-                snap = (self.params.clone(), self.m.clone(), None if self.v is None else self.v.clone())
                 with torch.cuda.stream(s):
                     self._train(1, min(steps, 2), n)
                 torch.cuda.current_stream().wait_stream(s)

@@ -221,6 +221,11 @@ def test_client_groups_match_the_plain_pipeline(monkeypatch):
     d0, tl0, vl0, c0, sl0 = out[0]
     noise = ((out[1][0] - d0).norm(dim=1) / d0.norm(dim=1)).max().item()       # one group, graph vs eager launches
     print(f"per-client update difference between two runs of the SAME schedule: up to {noise:.3g}")
+    if noise > 0:
+        for sl in h.layout.slots:
+            a, b = out[1][0][:, sl.offset:sl.offset + sl.numel], d0[:, sl.offset:sl.offset + sl.numel]
+            pc = (a - b).norm(dim=1) / b.norm(dim=1).clamp(min=1e-20)
+            print(f"  {sl.name}: clients off {(pc > 1e-6).nonzero().flatten().tolist()}")
     # losses (16 validation samples per client) move with those flips: tolerances from the same-schedule pair
     tol = [max(5e-2, 4 * (out[1][i] - out[0][i]).abs().max().item()) for i in (1, 2, 4)]
     for d, tl, vl, c, sl in out[1:]:

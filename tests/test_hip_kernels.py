@@ -737,3 +737,169 @@ def test_linear_wgrad_sgdm_against_torch_optim(K, B, In, Out, wd):
     for k in range(K):
         assert torch.allclose(w[k], ref_w[k].detach(), atol=1e-6, rtol=1e-5)
         assert torch.allclose(b[k], ref_b[k].detach(), atol=1e-6, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 3: optimizer steps folded into the gradient-producing kernels, the one-kernel classification head
+# ------------------------------------------------------------------------------------------------------------------
+def _slabs(K, P, n=3):
+    """n [K, P + pad] slabs with a common row stride (parameters, first / second moment)."""
+    stride = -(-P // 64) * 64 + 64
+    return [torch.randn(K, stride, device=DEV) * 0.1 for _ in range(n)]
+
+
+@pytest.mark.parametrize("K,B,nv,In,C,mask", [(3, 32, 32, 2048, 10, True), (2, 32, 12, 128, 10, True),
+                                              (2, 20, 20, 3136, 16, False), (5, 7, 5, 260, 3, True)])
+@pytest.mark.parametrize("kind", [None, "adam", "sgd"])
+def test_linear_head_matches_torch(K, B, nv, In, C, mask, kind):
+    """csrc/head.hip against autograd: logits, loss / accuracy / confusion counters, data gradient with the ReLU mask,
+    and either the parameter gradients or one step of torch.optim on (W, b)."""
+    h = hip()
+    assert h.linear_head_accepts(B, In, C)
+    n = 50
+    P = C * In
+    off_b = -(-P // 64) * 64
+    p, m, v = _slabs(K, off_b + 64)
+    m.abs_(); v.abs_()
+    W = lambda s: s[:, :P].unflatten(1, (C, In))
+    Bv = lambda s: s[:, off_b:off_b + C]
+    x = torch.randn(K, B, In, device=DEV)
+    if mask:
+        x = x.relu()
+    labels = torch.randint(0, C, (K, n), device=DEV).int()
+    sidx = torch.stack([torch.randperm(n, device=DEV)[:B] for _ in range(K)]).int()
+    nvt = torch.full((K,), nv, dtype=torch.int32, device=DEV)
+    loss_sum = torch.zeros(K, device=DEV)
+    correct = torch.zeros(K, dtype=torch.int32, device=DEV)
+    count = torch.zeros(K, dtype=torch.int32, device=DEV)
+    conf = torch.zeros(K, C, C, dtype=torch.int32, device=DEV)
+    dx = torch.full((K, B, In), 7.0, device=DEV)
+    logits = torch.zeros(K, B, C, device=DEV)
+    p0, m0, v0 = p.clone(), m.clone(), v.clone()
+    hyper = dict(lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-3)
+    t = 3
+    if kind is None:
+        g = torch.zeros_like(p)
+        h.linear_head(x, W(p), Bv(p), labels, sidx, loss_sum, correct, count, conf, nvt, dx=dx, dw=W(g), db=Bv(g),
+                      logits=logits, relu_mask=mask)
+    else:
+        opt = h.fold_opt(kind, W(p), W(m), W(v), Bv(p), Bv(m), Bv(v), momentum=0.9, t=t, **hyper)
+        h.linear_head(x, W(p), Bv(p), labels, sidx, loss_sum, correct, count, conf, nvt, dx=dx, logits=logits,
+                      relu_mask=mask, opt=opt)
+    torch.cuda.synchronize()
+    for k in range(K):
+        w_ref = W(p0)[k].clone().requires_grad_(True)
+        b_ref = Bv(p0)[k].clone().requires_grad_(True)
+        x_ref = x[k].clone().requires_grad_(True)
+        z = x_ref @ w_ref.T + b_ref
+        y = labels[k][sidx[k].long()].long()
+        loss = F.cross_entropy(z[:nv], y[:nv], reduction="sum")
+        (loss / nv).backward()
+        assert rel_err(logits[k][:nv], z[:nv].detach()) < 2e-5
+        assert abs(loss_sum[k].item() - loss.item()) < 1e-4 * max(1.0, abs(loss.item()))
+        pred = z[:nv].argmax(1)
+        assert correct[k].item() == int((pred == y[:nv]).sum()) and count[k].item() == nv
+        ref_conf = torch.zeros(C, C, dtype=torch.int32, device=DEV)
+        ref_conf.view(-1).index_add_(0, y[:nv] * C + pred, torch.ones(nv, dtype=torch.int32, device=DEV))
+        assert torch.equal(conf[k], ref_conf)
+        gx = x_ref.grad * (x[k] > 0) if mask else x_ref.grad
+        assert rel_err(dx[k], gx) < 2e-5
+        if kind is None:
+            assert rel_err(W(g)[k], w_ref.grad) < 2e-5 and rel_err(Bv(g)[k], b_ref.grad) < 2e-5
+            assert torch.equal(p, p0)
+            continue
+        # one step of the real optimizer from the same state
+        pw, pb = W(p0)[k].clone().requires_grad_(True), Bv(p0)[k].clone().requires_grad_(True)
+        pw.grad, pb.grad = w_ref.grad.clone(), b_ref.grad.clone()
+        if kind == "adam":
+            o = torch.optim.Adam([pw, pb], lr=hyper["lr"], betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3)
+            for q, mm, vv in ((pw, W(m0)[k], W(v0)[k]), (pb, Bv(m0)[k], Bv(v0)[k])):
+                o.state[q] = {"step": torch.tensor(float(t - 1)), "exp_avg": mm.clone(), "exp_avg_sq": vv.clone()}
+        else:
+            o = torch.optim.SGD([pw, pb], lr=hyper["lr"], momentum=0.9, weight_decay=1e-3)
+            for q, mm in ((pw, W(m0)[k]), (pb, Bv(m0)[k])):
+                o.state[q] = {"momentum_buffer": mm.clone()}
+        o.step()
+        assert torch.allclose(W(p)[k], pw.detach(), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(Bv(p)[k], pb.detach(), rtol=1e-5, atol=1e-6)
+        st = o.state[pw]
+        assert rel_err(W(m)[k], st["exp_avg" if kind == "adam" else "momentum_buffer"]) < 2e-5
+        if kind == "adam":
+            assert rel_err(W(v)[k], st["exp_avg_sq"]) < 2e-5
+    # nothing outside the layer's columns moved
+    assert torch.equal(p[:, P:off_b], p0[:, P:off_b]) and torch.equal(p[:, off_b + C:], p0[:, off_b + C:])
+
+
+@pytest.mark.parametrize("kind", ["adam", "sgd"])
+@pytest.mark.parametrize("ks,B,K", [(5, 32, 3), (7, 9, 2), (5, 32, 100)])
+def test_conv1_wgrad_folded_optimizer_matches_unfused(ks, B, K, kind, prec):
+    """The finishing pass of the stage-1 weight gradient applies the optimizer step itself: identical (bitwise) to the
+    gradient store followed by the element-wise optimizer kernel, and the gradient pass is bitwise reproducible."""
+    h = hip()
+    Fm, n = 32, 40
+    T = ks * ks
+    off_b = -(-Fm * T // 64) * 64
+    p, m, v = _slabs(K, off_b + 64)
+    v.abs_()
+    W = lambda s: s[:, :Fm * T].unflatten(1, (Fm, T))
+    Bv = lambda s: s[:, off_b:off_b + Fm]
+    data = torch.rand(K, n, 784, device=DEV)
+    sidx = torch.stack([torch.randperm(n, device=DEV)[:B] for _ in range(K)]).int()
+    g = torch.randn(K, B, Fm, 196, device=DEV)
+    code = torch.randint(0, 5, (K, B, Fm, 196), device=DEV).to(torch.uint8)
+    grads = torch.zeros_like(p)
+    h.conv1_wgrad(g, code, data, sidx, W(grads), Bv(grads), ks)
+    again = torch.zeros_like(p)
+    h.conv1_wgrad(g, code, data, sidx, W(again), Bv(again), ks)
+    assert torch.equal(grads, again)                         # fixed-order reduction: no atomics any more
+    p1, m1, v1 = p.clone(), m.clone(), v.clone()
+    hyper = dict(lr=1e-2, weight_decay=1e-3)
+    if kind == "adam":
+        h.adam_step(p1, grads, m1, v1, t=4, **hyper)
+    else:
+        h.sgdm_step(p1, grads, m1, momentum=0.9, **hyper)
+    opt = h.fold_opt(kind, W(p), W(m), W(v), Bv(p), Bv(m), Bv(v), momentum=0.9, t=4, **hyper)
+    h.conv1_wgrad(g, code, data, sidx, None, None, ks, opt=opt)
+    cols = torch.zeros(p.shape[1], dtype=torch.bool, device=DEV)
+    cols[:Fm * T] = True
+    cols[off_b:off_b + Fm] = True
+    # (same arithmetic; the compiler contracts multiply-adds differently in the two kernels: last-bit differences)
+    assert rel_err(p[:, cols], p1[:, cols]) < 2e-6 and rel_err(m[:, cols], m1[:, cols]) < 2e-6
+    if kind == "adam":
+        assert rel_err(v[:, cols], v1[:, cols]) < 2e-6
+
+
+@pytest.mark.parametrize("kind", ["adam", "sgd"])
+@pytest.mark.parametrize("ks,B,K", [(5, 32, 3), (3, 7, 9), (5, 4, 60), (5, 32, 100)])
+def test_conv2_wgrad_folded_optimizer_matches_unfused(ks, B, K, kind, prec):
+    h = hip()
+    Cin, Cout = 32, 64
+    T = ks * ks
+    P = Cout * Cin * T
+    off_b = -(-P // 64) * 64
+    p, m, v = _slabs(K, off_b + 64)
+    v.abs_()
+    W = lambda s: s[:, :P].unflatten(1, (Cout, Cin * T))
+    Bv = lambda s: s[:, off_b:off_b + Cout]
+    a1 = torch.randn(K, B, Cin, 196, device=DEV).relu()
+    g = torch.randn(K, B, Cout, 49, device=DEV)
+    code = torch.randint(0, 5, (K, B, Cout, 49), device=DEV).to(torch.uint8)
+    grads = torch.zeros_like(p)
+    h.conv2_wgrad(g, code, a1, W(grads), Bv(grads), ks)
+    p1, m1, v1 = p.clone(), m.clone(), v.clone()
+    p_before = p.clone()
+    hyper = dict(lr=1e-2, weight_decay=1e-3)
+    if kind == "adam":
+        h.adam_step(p1, grads, m1, v1, t=2, **hyper)
+    else:
+        h.sgdm_step(p1, grads, m1, momentum=0.9, **hyper)
+    opt = h.fold_opt(kind, W(p), W(m), W(v), Bv(p), Bv(m), Bv(v), momentum=0.9, t=2, **hyper)
+    h.conv2_wgrad(g, code, a1, None, None, ks, opt=opt)
+    cols = torch.zeros(p.shape[1], dtype=torch.bool, device=DEV)
+    cols[:P] = True
+    cols[off_b:off_b + Cout] = True
+    # (same arithmetic; the compiler contracts multiply-adds differently in the two kernels: last-bit differences)
+    assert rel_err(p[:, cols], p1[:, cols]) < 2e-6 and rel_err(m[:, cols], m1[:, cols]) < 2e-6
+    if kind == "adam":
+        assert rel_err(v[:, cols], v1[:, cols]) < 2e-6
+    assert torch.equal(p[:, ~cols], p_before[:, ~cols])          # nothing outside the layer's columns moved

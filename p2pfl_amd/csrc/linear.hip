@@ -707,6 +707,15 @@ P2PFL_API int p2pfl_linear_wgrad_adam(const float* dy, long dy_cs, const float* 
     P2PFL_RETURN_LAST_ERROR();
 }
 
+// Does the fused update + data gradient take K clients of a B x In x Out layer (the occupancy rule below; alignment of
+// the actual buffers is checked by the launch itself)? The engine sizes its client groups with this very rule.
+P2PFL_API int p2pfl_linear_wgrad_adam_dgrad_accepts(int K, int B, int In, int Out) {
+    if (K <= 0 || B <= 0 || In <= 0 || Out <= 0 || B > GEMM_BK || (In & 3) || K > 65535) return 0;
+    const char* fe = getenv("P2PFL_FUSE_DGRAD_FORCE");
+    if (fe && atoi(fe) != 0) return 1;
+    return (long)cdiv(In + 1, 128) * K >= 3L * num_cus();
+}
+
 // Fused update + data gradient (fp32 policies; see linear_wgrad_adam_dgrad_kernel). Returns -4 when the shape is
 // outside what the kernel covers (the caller then runs linear_dgrad + linear_wgrad_adam): B <= 32, In % 4 == 0,
 // 16-byte aligned weight / dx rows.

@@ -128,6 +128,7 @@ class _Sig:
     p2pfl_conv2_wgrad_opt = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, I, I, P, P]
     p2pfl_linear_head = [P, L, P, L, P, L, P, L, P, L, P, L, P, L, P, L, P, L, P, P, P, P, P, L, I, I, I, I, I, P, P]
     p2pfl_linear_head_accepts = [I, I, I]
+    p2pfl_linear_wgrad_adam_dgrad_accepts = [I, I, I, I]
     p2pfl_conv2_prep = [P, L, P, L, I, I, I, I, I, P]
     p2pfl_conv2_fwd = [P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, I, I, P]
     p2pfl_conv2_wgrad = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, I, I, P]
@@ -474,6 +475,11 @@ def softmax_ce(logits, labels, sidx, dlogits, loss_sum, correct, count, confusio
                                  _t(correct, torch.int32).data_ptr(), _t(count, torch.int32).data_ptr(),
                                  None if confusion is None else _t(confusion, torch.int32).data_ptr(),
                                  nvp, nvs, K, B, C, _stream()), "softmax_ce")
+
+
+def linear_wgrad_adam_dgrad_accepts(K: int, B: int, In: int, Out: int) -> bool:
+    """Would :func:`linear_wgrad_adam_dgrad` take K clients of this layer (its chip-filling rule, csrc/linear.hip)?"""
+    return bool(load().p2pfl_linear_wgrad_adam_dgrad_accepts(K, B, In, Out))
 
 
 def linear_head_accepts(B: int, In: int, C: int) -> bool:

@@ -17,7 +17,10 @@ Both share the slab layout, so aggregation / exchange code is engine-agnostic.
 from __future__ import annotations
 
 import math
+import atexit
+import logging
 import os
+import weakref
 from collections.abc import Mapping
 from dataclasses import dataclass
 from typing import Dict, List, Optional
@@ -292,12 +295,35 @@ class EagerEngine(ShardEngine):
 # ======================================================================================
 # HIP engine
 # ======================================================================================
+# Engines alive in this process: weak references to the ENGINES (plain Python objects), never to their streams or
+# graphs. Round 2 kept weak references to the ``torch.cuda.Stream`` objects themselves and big shards then died in the
+# interpreter's FINAL collection ("Fatal Python error: Segmentation fault ... Garbage-collecting"): at that point
+# nothing orders the destructors - captured graphs (hipGraphExecDestroy), their streams and the weak-reference
+# callbacks run in whatever order the collector finds them, possibly with replays still in flight and with parts of
+# torch already torn down. What the trace shows is only "device objects destroyed during finalization"; which
+# destructor faults was not isolated. The fix therefore removes the situation instead of one suspect: ownership is
+# explicit - ``close()`` synchronises the device, drops the graphs, then the side stream - and ``_close_live_engines``
+# runs it from ``atexit``, i.e. BEFORE finalization starts and with the HIP runtime alive, so the final collection
+# only ever sees engines that hold no device objects.
+_LIVE_ENGINES: "weakref.WeakSet" = weakref.WeakSet()
+
+
+def _close_live_engines() -> None:
+    for eng in list(_LIVE_ENGINES):
+        try:
+            eng.close()
+        except Exception:     # noqa: BLE001 - shutting down: nothing useful to do with an error here
+            pass
+
+
+atexit.register(_close_live_engines)
+
+
 def pending_stream_events():
     """(engine id, event name) of the first unsignalled debug events of every live engine (P2PFL_STREAM_DEBUG=1)."""
-    import gc
     out = []
-    for obj in gc.get_objects():
-        if isinstance(obj, HipEngine) and obj._stream_debug:
+    for obj in list(_LIVE_ENGINES):
+        if obj._stream_debug:
             names = [(n, ev.query()) for n, ev in obj._stream_debug]
             done = sum(1 for _, q in names if q)
             out.append((id(obj), done, len(names), [n for n, q in names if not q][:4]))
@@ -306,14 +332,9 @@ def pending_stream_events():
 
 def live_aux_streams():
     """(role, stream) of every auxiliary HIP stream of the engines alive in this process - for the stall
-    diagnostics (tests/conftest.py, tools/diag_streams.py). Found through the garbage collector on demand: a
-    registry of weak references to the streams crashed the interpreter's final collection with big shards."""
-    import gc
-    out = []
-    for obj in gc.get_objects():
-        if isinstance(obj, HipEngine) and getattr(obj, "overlap", False):
-            out.append(("side", obj._side))
-    return out
+    diagnostics (tests/conftest.py, tools/diag_streams.py)."""
+    return [("side", obj._side) for obj in list(_LIVE_ENGINES)
+            if getattr(obj, "overlap", False) and getattr(obj, "_side", None) is not None]
 
 
 class HipEngine(ShardEngine):
@@ -468,14 +489,23 @@ class HipEngine(ShardEngine):
         self._wgrad_on_main = (self.overlap and self.nc >= 2 and self.spec.layers[self.nc - 1].kind == "conv2pool"
                                and (self.precision == "fp32" if env is None else env != "0"))
         self._wgrad_ev = None
+        _LIVE_ENGINES.add(self)
 
     def close(self) -> None:
-        """Release the captured graphs now (while the HIP runtime is certainly alive) instead of at
-        interpreter shutdown."""
-        if self.device.type == "cuda" and (self._graphs or self._eval_graph is not None):
+        """Release the captured graphs and then the side stream now (while the HIP runtime is certainly alive, after a
+        device synchronise) instead of at interpreter shutdown; idempotent, also run from ``atexit``."""
+        if self.device.type == "cuda" and (self._graphs or self._eval_graph is not None
+                                           or getattr(self, "_side", None) is not None):
             torch.cuda.synchronize(self.device)
         self._graphs.clear()
         self._eval_graph = None
+        self._wgrad_ev = None
+        if self._stream_debug:
+            self._stream_debug.clear()
+        if getattr(self, "_side", None) is not None:
+            self._side = None
+            self.overlap = False          # (a closed engine that is used again runs the single-stream schedule)
+        _LIVE_ENGINES.discard(self)
 
     EVAL_B = 256
 
@@ -992,12 +1022,27 @@ class HipEngine(ShardEngine):
         self._step_pos = views[0]._step_pos
 
     def _groups(self) -> int:
-        """Client groups of the two-stream schedule: 2 when every group still takes the fused update + data gradient
-        (>= 31 clients each, see csrc/linear.hip; measured from 2 x 32 clients up: tools/probe/groups_k.sh) - ``P2PFL_GROUPS`` overrides (1: one group, the plain pipeline)."""
+        """Client groups of the two-stream schedule: 2 when the SMALLEST group still takes the fused update + data
+        gradient - asked of the kernel's own chip-filling rule (``p2pfl_linear_wgrad_adam_dgrad_accepts``: MNIST-CNN l1
+        on 256 CUs = 31 clients per group; measured from 2 x 32 clients up, tools/probe/groups_k.sh), so another layer
+        width or CU count moves the threshold with it. ``P2PFL_GROUPS`` overrides (1: one group, the plain pipeline); a
+        forced split whose groups fall back to data gradient + separate update is logged once."""
+        first_dense = self.spec.layers[self.nc] if self.nc < len(self.spec.layers) else None
+
+        def accepted(G: int) -> bool:
+            return (first_dense is not None and first_dense.kind == "linear" and self.K // G >= 1
+                    and self.hip.linear_wgrad_adam_dgrad_accepts(self.K // G, self.B, first_dense.in_features,
+                                                                 first_dense.out_features))
         env = os.environ.get("P2PFL_GROUPS")
         if env is not None:
-            return max(1, min(int(env), self.K))
-        return 2 if (self._fuse_dgrad and self.K >= 62 and self.spec.optim.kind == "adam") else 1
+            G = max(1, min(int(env), self.K))
+            if G > 1 and self._fuse_dgrad and not accepted(G) and not getattr(self, "_groups_warned", False):
+                self._groups_warned = True
+                logging.warning("[HipEngine] P2PFL_GROUPS=%d: groups of %d clients are below what the fused update + data "
+                                "gradient takes; every group runs linear_dgrad + the separate update (measured slower)",
+                                G, self.K // G)
+            return G
+        return 2 if (self._fuse_dgrad and self.spec.optim.kind == "adam" and accepted(2)) else 1
 
     def _train(self, epochs: int, steps: int, n: int) -> None:
         self._step_pos = 0

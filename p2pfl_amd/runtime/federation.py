@@ -141,12 +141,22 @@ class BatchedFederation:
             self.weights[:] = np.asarray(n_train_all, dtype=np.float64)
 
     def fast_forward(self, first_round: int) -> None:
-        """Resume at ``first_round``: the faults of the rounds already done are applied (with the clock moving as
-        if those rounds had run), the round and per-round shuffle counters continue - no training."""
+        """Resume at ``first_round``: the faults of the rounds already done are applied and the membership clock moves
+        as it did when those rounds ran - per replayed round the start faults, the mid-round faults, the round
+        structure (which aggregators waited in vain for a dead member) and then one heartbeat period plus
+        AGGREGATION_TIMEOUT when somebody timed out, which is what evicts dead nodes - so ``believed`` / evictions, the
+        ``late`` tie-break of adopting nodes after ``--resume`` are those of the uninterrupted run (roles, i.e. the
+        SDFL leader, come from the checkpoints). No training; the round and per-round shuffle counters continue."""
         for r in range(self.round, first_round):
-            self.membership.apply_round(r, None)
-            self.membership.advance(self.membership.period)
-        self._sync_membership()
+            self.round = r
+            self._apply_faults("start")
+            self._apply_faults("mid")
+            self._round_structure()
+            timed_out = list(self.timed_out)
+            for i in timed_out:
+                self.membership.note("aggregation_timeout", i)
+            self.membership.advance(self.membership.period + (self.aggregation_timeout if timed_out else 0.0))
+            self._sync_membership()
         self.round = first_round
         self.engine._perm_calls = first_round
 

@@ -103,6 +103,7 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    control_plane = bool(control_plane or gateways)      # a gateway implies the control plane (one status POST path)
     if device == "auto":
         device = "cuda" if torch.cuda.is_available() else "cpu"
     dev = torch.device(device, local_rank) if device == "cuda" else torch.device("cpu")

@@ -140,11 +140,14 @@ class ModuleEngine(ShardEngine):
         # hipGraph replay of a whole batched pass (an epoch of steps incl. backward and optimizer, or an evaluation
         # pass): small families are launch-bound even client-batched (50 SYSCALL MLPs: ~50 kernels of microseconds per
         # step). A pass runs eagerly the first time (lazy initialisation, MIOpen search), is captured at its second
-        # occurrence and replayed from then on. Not with an augmentation hook (see below). P2PFL_MODULE_GRAPH=0 keeps the passes eager.
-        # (Measured: capturing a training pass that contains the CIFAR-10 crop / flip gather ends in a segmentation
-        # fault inside hipStreamEndCapture on ROCm 7.2 - passes with an augmentation hook stay eager.)
-        self.use_graph = (self.device.type == "cuda" and spec.augment is None
-                          and os.environ.get("P2PFL_MODULE_GRAPH", "1") != "0")
+        # occurrence and replayed from then on. P2PFL_MODULE_GRAPH=0 keeps the passes eager.
+        # A pass is captured as SEGMENTS of at most ``graph_steps`` steps: hipStreamEndCapture of ROCm 7.2 dies with a
+        # segmentation fault on very long captures - bisected with tools/probe/capture_augment.py: every piece of the
+        # CIFAR-10 crop / flip augmentation (pad, device RNG, index arithmetic, the 4-index gather) captures fine, and
+        # so do 8- and 64-step SimpleMobileNet passes WITH the hook; the 390-step pass of a 4-node CIFAR-10 split
+        # (~10^5 kernel nodes in one graph) is what faults, with or without augmentation.
+        self.use_graph = self.device.type == "cuda" and os.environ.get("P2PFL_MODULE_GRAPH", "1") != "0"
+        self.graph_steps = max(1, int(os.environ.get("P2PFL_MODULE_GRAPH_STEPS", "32")))
         self._graphs: Dict[tuple, object] = {}
         self._seen: set = set()
         self._gstate = None
@@ -314,13 +317,18 @@ class ModuleEngine(ShardEngine):
                 self._graphs = {k: g for k, g in self._graphs.items() if not k[1]}      # training graphs read it
             self._perm_static.copy_(order)
             order_static = self._perm_static
-        g = self._graphs.get(key)
-        if g is None:
+        segs = self._graphs.get(key)
+        if segs is None:
+            n, span = x.shape[1], self.graph_steps * self.B
+            segs = []
             try:
                 torch.cuda.synchronize(self.device)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    self._phase_batched_inner(self._gstate, x, y, phase, train, optim, order_static)
+                for lo in range(0, n, span):                # one graph per <= graph_steps steps (see __init__)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        self._phase_batched_inner(self._gstate, x, y, phase, train, optim, order_static,
+                                                  lo, min(n, lo + span))
+                    segs.append(g)
             except Exception as exc:  # noqa: BLE001 - a family / optimizer that cannot be captured stays eager
                 logging.warning("[ModuleEngine] %s: hipGraph capture of the %s pass failed (%s); eager from here on",
                                 self.spec.name, phase, str(exc).splitlines()[0] if str(exc) else type(exc).__name__)
@@ -328,18 +336,22 @@ class ModuleEngine(ShardEngine):
                 self._graphs.clear()
                 torch.cuda.synchronize(self.device)
                 return False
-            self._graphs[key] = g
-        g.replay()
+            self._graphs[key] = segs
+            # (the capture itself executed nothing: the replay below is the pass)
+        for g in segs:
+            g.replay()
         if train:
             self._writeback(self._gstate)
         return True
 
-    def _phase_batched_inner(self, state, x, y, phase: str, train: bool, optim, order) -> None:
+    def _phase_batched_inner(self, state, x, y, phase: str, train: bool, optim, order, lo: int = 0,
+                             hi: Optional[int] = None) -> None:
+        """Steps of the pass whose first sample index lies in [lo, hi) (default: the whole pass)."""
         n = x.shape[1]
         m0 = self.modules[0]
         m0.train(train)
         kar = torch.arange(self.K, device=self.device).view(self.K, 1)
-        for s in range(0, n, self.B):
+        for s in range(lo, n if hi is None else min(hi, n), self.B):
             nb = min(self.B, n - s)
             if train and nb < 2:
                 continue                                     # BatchNorm cannot train on a single sample

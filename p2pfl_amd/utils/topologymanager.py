@@ -199,7 +199,8 @@ class TopologyManager:
         plt.close(fig)
 
     @staticmethod
-    def update_topology_3d_json(participants, path):
+    def update_topology_3d_json(participants, path=None):
+        """nodes / links document of the 3-D graph; written to ``path`` when one is given, always returned."""
         data = {"nodes": [], "links": []}
         for node in participants:
             ipport = node["network_args"]["ip"] + ":" + str(node["network_args"]["port"])
@@ -212,5 +213,7 @@ class TopologyManager:
             for nb in node["network_args"]["neighbors"].split(" "):
                 if nb != "":
                     data["links"].append({"source": src, "target": nb, "value": 1})
-        with open(path, "w") as f:
-            json.dump(data, f, sort_keys=False, indent=2)
+        if path is not None:
+            with open(path, "w") as f:
+                json.dump(data, f, sort_keys=False, indent=2)
+        return data

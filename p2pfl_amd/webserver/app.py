@@ -68,7 +68,14 @@ def _ingest_allowed(scenario_name):
         return False
     with open(tok_path) as f:
         want = f.read().strip()
-    got = request.headers.get("X-Scenario-Token", "")
+    # header (this repo's nodes), or - for reference-protocol nodes, whose POST carries no such header - the same
+    # token inside the posted participant config (``scenario_args.controller_token``, which the controller wrote
+    # into the file the node was started from and which the node echoes back) or as ``?token=`` of the URL
+    got = request.headers.get("X-Scenario-Token", "") or request.args.get("token", "")
+    if not got:
+        body = request.get_json(force=True, silent=True)
+        if isinstance(body, dict):
+            got = str((body.get("scenario_args") or {}).get("controller_token") or "")
     import hmac
     return bool(want) and hmac.compare_digest(want, got)
 
@@ -287,9 +294,12 @@ def update_topology(scenario_name, nodes):
 def fedstellar_api_topology(scenario_name):
     """Live topology as the reference's 3-D graph JSON (``TopologyManager.update_topology_3d_json``,
     utils/topologymanager.py:321-354: nodes {uid,id,ipport,role,ip,port,start} + links {source,target,value}) built
-    from the nodes' last status reports, plus each node's coordinates and liveness for the map overlay. A copy is
-    kept as ``<config_dir>/<scenario>/topology.json`` like the reference's (commented-out) call at app.py:383."""
+    from the nodes' last status reports, plus each node's coordinates and liveness for the map overlay. Needs a
+    session (or the scenario token): the document names every node's address and role. Read-only - nothing is
+    written from this GET."""
     cdir = _under(app.config["config_dir"], scenario_name)
+    if "user" not in session and not _ingest_allowed(scenario_name):
+        return abort(401)
     rows = _node_rows(scenario_name)
     starts = {}
     for path in glob.glob(os.path.join(cdir, "participant_*.json")):
@@ -301,12 +311,7 @@ def fedstellar_api_topology(scenario_name):
             continue
     participants = [{"device_args": {"uid": r["uid"], "idx": r["idx"], "role": r["role"], "start": starts.get(int(r["idx"]), False)},
                      "network_args": {"ip": r["ip"], "port": r["port"], "neighbors": r["neighbors"] or ""}} for r in rows]
-    path = os.path.join(cdir, "topology.json")
-    data = {"nodes": [], "links": []}
-    if os.path.isdir(cdir):
-        TopologyManager.update_topology_3d_json(participants, path)
-        with open(path) as f:
-            data = json.load(f)
+    data = TopologyManager.update_topology_3d_json(participants) if os.path.isdir(cdir) else {"nodes": [], "links": []}
     known = {n["ipport"] for n in data["nodes"]}
     data["links"] = [l for l in data["links"] if l["target"] in known]
     for n, r in zip(data["nodes"], rows):

@@ -172,6 +172,36 @@ def test_dropped_link_and_paused_node_change_the_train_sets():
     assert [e[1] for e in fed.membership.events] == ["pause", "resume"]
 
 
+def test_fast_forward_replays_the_membership_clock_of_the_finished_rounds():
+    """--resume under churn with the reference's detection (NODE_TIMEOUT after the last beat): the replayed rounds
+    charge AGGREGATION_TIMEOUT where an aggregator waited in vain, so evictions - and with them the train sets of the
+    first resumed round - are those of the run that was never interrupted."""
+    def build():
+        fed = BatchedFederation(SPEC, topo("ring", 6), device="cpu", engine="eager", epochs=1, seed=5,
+                                instant_detection=False, aggregation_timeout=60.0, node_timeout=20.0)
+        fed.init_params()
+        fed.set_local_data(*synthetic_shards(6, 32, 8, 16, 10, seed=1))
+        perturb(fed)
+        fed.schedule_fault(1, "kill", 3)
+        fed.schedule_fault(2, "kill", 5, phase="mid")
+        fed.schedule_fault(4, "revive", 3)
+        return fed
+    full = build()
+    for _ in range(4):
+        full.run_round(evaluate=False)
+    resumed = build()
+    resumed.fast_forward(4)
+    strip = lambda ev: [(what, node) for _, what, node in ev]
+    assert strip(resumed.membership.events) == strip(full.membership.events)
+    assert ("evicted", 3) in strip(full.membership.events) and ("aggregation_timeout", 2) in strip(full.membership.events)
+    assert (resumed.believed == full.believed).all() and (resumed.alive == full.alive).all()
+    assert resumed.round == full.round == 4
+    assert [resumed.train_set(i) for i in range(6)] == [full.train_set(i) for i in range(6)]
+    # round 4 revives node 3 on both
+    full.run_round(evaluate=False); resumed.run_round(evaluate=False)
+    assert strip(resumed.membership.events) == strip(full.membership.events)
+
+
 # ------------------------------------------------------------------ 2 ranks over gloo
 def _free_port():
     s = socket.socket()

@@ -56,10 +56,15 @@ def test_scenario_on_the_hip_engine(tmp_path, dataset, model, federation, topolo
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ds,model", [("SYSCALL", "MLP"), ("SYSCALL", "SVM"), ("WADI", "MLP")])
-def test_module_engine_graph_replay_matches_eager_batched_passes(ds, model, monkeypatch):
+@pytest.mark.parametrize("ds,model,seg", [("SYSCALL", "MLP", None), ("SYSCALL", "SVM", None), ("WADI", "MLP", None),
+                                          ("SYSCALL", "MLP", 2)])
+def test_module_engine_graph_replay_matches_eager_batched_passes(ds, model, seg, monkeypatch):
     """ModuleEngine on the GPU: passes replayed as hipGraphs (captured at their second occurrence; the optimizer object
-    kept and reset in place per round) against the same client-batched passes launched eagerly."""
+    kept and reset in place per round) against the same client-batched passes launched eagerly. ``seg``: a pass split
+    into graph segments of that many steps (how long passes are captured: one graph of a 390-step CIFAR-10 pass
+    crashes hipStreamEndCapture, tools/probe/capture_augment.py)."""
+    if seg:
+        monkeypatch.setenv("P2PFL_MODULE_GRAPH_STEPS", str(seg))
     import torch
     from p2pfl_amd.node_start import build_dataset_and_model, build_model
     from p2pfl_amd.runtime.module_engine import ModuleEngine, ModuleSpec
@@ -93,6 +98,8 @@ def test_module_engine_graph_replay_matches_eager_batched_passes(ds, model, monk
         assert torch.equal(res["0"][2], res["1"][2])
     g = engines["1"]
     assert g.use_graph and len(g._graphs) >= 3          # test pass, training epoch, validation pass
+    if seg:                                             # 96 samples = 3 steps: two segments per training pass
+        assert max(len(v) for v in g._graphs.values()) == 2
     assert torch.equal(g.params[2], engines["0"].params[2])          # the idle node kept its (identical) model
     g.set_data(*data)
     assert not g._graphs                                 # new data: the captured passes are dropped

@@ -362,8 +362,18 @@ def test_designer_node_fields_topology_json_and_event_file_statistics(web, monke
     assert t["nodes"][0]["start"] is True and t["nodes"][1]["role"] == "aggregator" and t["nodes"][2]["status"] is True
     assert float(t["nodes"][2]["longitude"]) == 9.0
     assert len(t["links"]) == 6 and {"source": "127.0.0.1:47100", "target": "127.0.0.1:47101", "value": 1} in t["links"]
-    assert json.loads((tmp / "config" / name / "topology.json").read_text())["links"]
+    assert not (tmp / "config" / name / "topology.json").exists()          # a GET writes nothing
     assert c.get("/api/scenario/../topology").status_code in (400, 404)
+    # a reference-protocol node sends no X-Scenario-Token header: the token inside the posted config is accepted too
+    cfg = json.loads((tmp / "config" / name / "participant_1.json").read_text())
+    assert cfg["scenario_args"]["controller_token"] == tok["X-Scenario-Token"]
+    assert c.post(f"/scenario/{name}/node/update", data=json.dumps(cfg), content_type="application/json").status_code == 200
+    cfg["scenario_args"]["controller_token"] = "wrong"
+    assert c.post(f"/scenario/{name}/node/update", data=json.dumps(cfg), content_type="application/json").status_code == 403
+    # the topology document names addresses and roles: no session and no token -> 401
+    with appmod.app.test_client() as anon:
+        assert anon.get(f"/api/scenario/{name}/topology").status_code == 401
+        assert anon.get(f"/api/scenario/{name}/topology", headers=tok).status_code == 200
     # event files only (no metrics.csv): the statistics API still has the scalars
     from p2pfl_amd.learning.pytorch.statisticslogger import FedstellarLogger
     lg = FedstellarLogger(str(tmp / "logs" / name), name="metrics", version="participant_1")

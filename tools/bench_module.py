@@ -38,7 +38,7 @@ for ds, model, K, n in CASES:
             float(out["Train"]["loss"].mean())
             torch.cuda.synchronize()
             times[mode] = time.perf_counter() - t0
-            assert eng.batched == (mode != "loop") and (mode != "vmap+graph" or eng.use_graph == (spec.augment is None))
+            assert eng.batched == (mode != "loop") and (mode != "vmap+graph" or eng.use_graph)
         except Exception as exc:  # noqa: BLE001
             times[mode] = float("nan")
             print(f"  {ds}-{model} {mode} failed: {type(exc).__name__}: {str(exc)[:200]}")

@@ -396,9 +396,7 @@ class Controller:
         env = dict(os.environ, PYTHONPATH=root)
         args = [self.config_dir] + (["--encrypt"] if self.encrypt else [])
         if self.control_plane or self.gateways:
-            if world > 1:
-                logging.warning("the control plane / TCP gateways serve one rank: running the scenario on 1 GPU")
-                world = 1
+            # (one FederationHost per rank, joined by the host-side rank bridge: runtime/host.py, runtime/bridge.py)
             args += ["--control-plane"] + [x for g in self.gateways for x in ("--gateway", str(g))]
             if self.wait_start is not None:
                 args += ["--wait-start", str(self.wait_start)]

@@ -231,9 +231,12 @@ class LightningLearner(NodeLearner):
                 eng.synchronize()
                 self._local_step = eng.steps_per_epoch() * self.epochs
                 per_step = eng.step_losses()
-                if per_step is not None:            # Train/Loss every 20 steps (lightninglearner.py:188)
+                if per_step is not None:            # the per-step series, every 20 steps (lightninglearner.py:188;
+                    per_cm = eng.step_metrics()     # mnist/models/mlp.py:33-106: loss + macro metrics of the batch)
                     for t in range(19, per_step.shape[0], 20):
-                        self._log({"Train/Loss": float(per_step[t, 0])}, step=t + 1)
+                        row = {"Train/Loss": float(per_step[t, 0])}
+                        row.update({f"Train/{k}": v for k, v in per_cm.get(t + 1, [{}])[0].items()})
+                        self._log(row, step=t + 1)
                 self._log_phase("Train", out["Train"]["loss"][0], out["Train"]["confusion"][0], self._local_step)
                 if "Validation" in out:
                     self._log_phase("Validation", out["Validation"]["loss"][0], out["Validation"]["confusion"][0],

@@ -346,8 +346,14 @@ class HipEngine(ShardEngine):
         # log_steps: keep the running (loss sum, sample count) of every optimizer step in a device table written
         # from inside the captured graph, so per-step Train/Loss can be reported like the reference's
         # log_every_n_steps=20 (lightninglearner.py:188) without leaving the graph
+        # ... and, every LOG_EVERY steps, the confusion counters of that step and of the step before it: their
+        # difference is the confusion matrix of ONE batch, from which the host derives the per-step
+        # Train/{Accuracy,Precision,Recall,F1Score} series of the reference's models (mnist/models/mlp.py:33-106:
+        # torchmetrics on the step's batch, logged every 20 steps)
         self.log_steps = bool(log_steps)
         self._step_log = None
+        self._step_cm = None
+        self._cm_slot: Dict[int, int] = {}
         if self.device.type != "cuda":
             raise RuntimeError("HipEngine needs a GPU device")
         from ..ops import hip
@@ -591,12 +597,49 @@ class HipEngine(ShardEngine):
         if train:
             self._record_step()
 
+    LOG_EVERY = 20
+
     def _record_step(self) -> None:
         if self._step_log is not None and self._step_pos < self._step_log.shape[0]:
             st = self.stats["Train"]
             self._step_log[self._step_pos, 0].copy_(st.loss_sum)
             self._step_log[self._step_pos, 1].copy_(st.count)
+            slot = self._cm_slot.get(self._step_pos)
+            if slot is not None and self._step_cm is not None:
+                self._step_cm[slot].copy_(st.confusion)
             self._step_pos += 1
+
+    def step_confusions(self) -> Dict[int, torch.Tensor]:
+        """{step (1-based, every LOG_EVERY-th): [K, C, C] confusion matrix of THAT step's batch} of the last ``fit``
+        (needs ``log_steps``): the difference of the counters snapshotted inside the graph after this step and after
+        the one before it."""
+        if self._step_cm is None:
+            return {}
+        cms = self._step_cm.cpu().to(torch.int64)
+        out = {}
+        for pos, slot in sorted(self._cm_slot.items()):
+            if (pos + 1) % self.LOG_EVERY:
+                continue
+            cur = cms[slot]
+            d = cur - (cms[self._cm_slot[pos - 1]] if pos - 1 in self._cm_slot else 0)
+            reset = d.flatten(1).min(dim=1).values < 0        # the per-epoch statistics were reset between the two steps
+            d[reset] = cur[reset]
+            out[pos + 1] = d
+        return out
+
+    def step_metrics(self) -> Dict[int, List[Dict[str, float]]]:
+        """{step: per-client macro Accuracy / Precision / Recall / F1Score of that step's batch} - the per-step
+        ``Train/*`` series of the reference's models (mnist/models/mlp.py:33-106), derived on the host."""
+        from ..learning.metrics import metrics_from_confusion
+        out = {}
+        for step, cm in self.step_confusions().items():
+            rows = []
+            for k in range(cm.shape[0]):
+                m = metrics_from_confusion(cm[k])
+                m.pop("MicroAccuracy", None)
+                rows.append(m)
+            out[step] = rows
+        return out
 
     def step_losses(self) -> Optional[torch.Tensor]:
         """[steps, K] mean training loss of every optimizer step of the last ``fit`` (needs ``log_steps``)."""
@@ -958,6 +1001,7 @@ class HipEngine(ShardEngine):
             v.stats = {ph: PhaseStats(st.loss_sum[sl], st.correct[sl], st.count[sl], st.confusion[sl])
                        for ph, st in self.stats.items()}
             v._step_log = None if self._step_log is None else self._step_log[:, :, sl]
+            v._step_cm = None if self._step_cm is None else self._step_cm[:, sl]
             # buffers with static addresses of their own (baked into the captured graph): kept on the engine
             own = keep.setdefault((G, g), {"nv": {}, "fwd": {}, "w2": None, "c1": None})
             if own["w2"] is None:
@@ -1079,6 +1123,10 @@ class HipEngine(ShardEngine):
             self._bc_buf.copy_(bc, non_blocking=True)
         if self.log_steps and (self._step_log is None or self._step_log.shape[0] != total):
             self._step_log = torch.zeros(total, 2, self.K, device=self.device)
+            logged = [p for p in range(total) if (p + 1) % self.LOG_EVERY == 0]
+            self._cm_slot = {p: i for i, p in enumerate(sorted({q for p in logged for q in (p - 1, p)}))}
+            C = self.stats["Train"].confusion.shape[-1]
+            self._step_cm = torch.zeros(max(len(self._cm_slot), 1), self.K, C, C, dtype=torch.int32, device=self.device)
             self._graphs.clear()
         saved = None
         if active is not None and not bool(torch.as_tensor(active).all()):

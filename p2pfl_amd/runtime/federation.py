@@ -70,7 +70,7 @@ class BatchedFederation:
                  overlap: bool = True, heartbeat_period: float = 4.0, node_timeout: float = 20.0,
                  instant_detection: bool = True, precision: Optional[str] = None,
                  aggregation_timeout: float = 60.0, virtual_devices: int = 1,
-                 block_sizes: Optional[Sequence[int]] = None):
+                 block_sizes: Optional[Sequence[int]] = None, log_steps: bool = False):
         self.spec = spec
         self.adj = np.asarray(topology, dtype=np.float32)
         self.N = self.adj.shape[0]
@@ -92,7 +92,10 @@ class BatchedFederation:
                                                seed=seed, persist_optimizer=persist_optimizer,
                                                client_offset=self.local.start,
                                                **({"use_graph": use_graph, "overlap": overlap, "precision": precision}
-                                                  if engine != "eager" else {}))
+                                                  if engine != "eager" else {}),
+                                               # per-step Train/* series (HIP engine: snapshots inside the graph)
+                                               **({"log_steps": True} if log_steps and engine != "eager"
+                                                  and isinstance(spec, ModelSpec) and self.device.type == "cuda" else {}))
         # membership of ALL nodes of the scenario (every rank applies the same deterministic schedule)
         self.membership = VirtualMembership(self.N, heartbeat_period, node_timeout, instant=instant_detection)
         self.alive = np.ones(self.N, dtype=bool)                # the node's process is up (it evaluates / trains)
@@ -106,6 +109,16 @@ class BatchedFederation:
         self.round = 0
         self.rng = random.Random(seed)                            # shared by all ranks (same seed)
         self.comm = DeviceExchange(rank, world_size, process_group, self.device, encrypt, scenario)
+        # Host-side group (gloo) next to the RCCL one: what the ranks have to AGREE on - the heartbeat table's evictions
+        # when they are timing-dependent (NODE_TIMEOUT detection), STOP_LEARNING, which nodes are TCP gateways - is a few
+        # bytes per round and never travels on the RCCL stream (see _sync_membership, runtime/host.py)
+        self.host_pg = None
+        if world_size > 1 and process_group is not None and not instant_detection:
+            self.ensure_host_group()
+        # False: never collapse the exchange into one all-reduce even when every aggregator shares one train set -
+        # a TCP gateway (runtime/host.py) needs the ROWS of its train set staged on its rank
+        self.allow_allreduce = True
+        self._row_of: Dict[int, int] = {}                      # node id -> row of the source pool of the current plan
         # >= 2: the nodes of this GPU are split into "virtual devices"; rows that cross from one to another take the
         # inter-GPU path of a multi-GPU job (gather -> link cipher -> staging -> decrypt -> reduce over local +
         # staged rows) although they never leave the card - config #4 (encrypted exchange) on a one-GPU box
@@ -116,6 +129,14 @@ class BatchedFederation:
         self._plan_cache: Dict[bytes, tuple] = {}
         self.trace = os.environ.get("P2PFL_TRACE", "0") not in ("", "0")   # roctx ranges around the phases
         self.reports: List[RoundReport] = []
+
+    def ensure_host_group(self):
+        """The gloo group of this job's ranks (the process group itself when that is gloo already). Collective: every
+        rank calls it at the same point."""
+        if self.host_pg is None and self.pg is not None and self.world > 1:
+            import torch.distributed as dist
+            self.host_pg = self.pg if dist.get_backend(self.pg) == "gloo" else dist.new_group(backend="gloo")
+        return self.host_pg
 
     # ------------------------------------------------------------------ setup
     def init_params(self, seed: Optional[int] = None, start_node: int = 0) -> None:
@@ -215,11 +236,13 @@ class BatchedFederation:
         h.update(self.delivered.tobytes())
         h.update(repr(sorted(self.membership.dropped)).encode())
         h.update("|".join(self.roles).encode())
+        h.update(b"1" if self.allow_allreduce else b"0")
         return h.digest()
 
     def _build_exchange(self, train_sets, adopt):
         """Exchange plan of this rank (see parallel/planner.py) in the tuple form ``aggregate`` caches."""
-        ep = plan_exchange(train_sets, adopt, self.owner, self.weights, self.rank, self.world, self.local)
+        ep = plan_exchange(train_sets, adopt, self.owner, self.weights, self.rank, self.world, self.local,
+                           allow_allreduce=self.allow_allreduce)
         if ep.mode == "allreduce":
             lo, dev = self.local.start, self.device
             plan = idx = None
@@ -232,7 +255,7 @@ class BatchedFederation:
             if ep.local_dests:
                 idx = torch.tensor([d - lo for d in ep.local_dests], device=dev)
             return ("allreduce", ep.local_sources, ep.local_weights, ep.local_dests, plan, idx)
-        return ("rows", ep.send_lists, ep.recv_lists, build_plan(ep.groups), ep.n_recv)
+        return ("rows", ep.send_lists, ep.recv_lists, build_plan(ep.groups), ep.n_recv, dict(ep.row_of))
 
     # ------------------------------------------------------------------ exchange
     def _exchange_rows(self, send_lists, recv_lists, n_recv: int) -> int:
@@ -259,6 +282,19 @@ class BatchedFederation:
     def _sync_membership(self) -> None:
         self.alive = self.membership.running().copy()
         self.believed = self.membership.believed().copy()
+        if self.host_pg is not None and not self.membership.instant:
+            # Faults are scheduled per round, so ``alive`` is the same on every rank by construction; WHEN the heartbeat
+            # table evicts a silent node depends on each rank's clock (wall time of its rounds / its timer wheel). The
+            # exchange plans of all ranks must describe one structure - what a sends to b is what b expects - so the
+            # ranks agree here, on the host-side group: a node is evicted everywhere as soon as one rank evicted it.
+            import torch.distributed as dist
+            t = torch.from_numpy(self.believed.astype(np.uint8))
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.host_pg)
+            self.believed = t.numpy().astype(bool)
+            late = self.membership.member & ~self.believed
+            for i in np.nonzero(late)[0]:
+                self.membership.member[i] = False
+                self.membership.events.append((self.membership.clock, "evicted", int(i)))
 
     def _range(self, name: str):
         """roctx range (visible in rocprofv3 --marker-trace) when P2PFL_TRACE=1."""
@@ -268,24 +304,42 @@ class BatchedFederation:
         return False
 
     def aggregate(self) -> int:
-        """Exchange + FedAvg for the current membership/roles. Returns #rows received from peers."""
+        """Exchange + FedAvg for the current membership/roles. Returns #rows received from peers.
+
+        ``pre_aggregate_hook`` (a FederationHost) runs BETWEEN the two: the rows of other ranks are staged by then, so
+        a TCP gateway can form the partial aggregate of its whole train set (local + staged rows) while the reduce of
+        the slab waits for the gateway's own aggregation."""
         eng = self.engine
+        hook = self.pre_aggregate_hook if self.pre_aggregate_hook is not None else (lambda fed: None)
         if self.virtual_devices > 1:
+            hook(self)
             return self._aggregate_virtual_devices()
         cached, all_covered = self._plan()
+        lo = self.local.start
+        self._row_of = cached[5] if (cached is not None and cached[0] == "rows") else {j: j - lo for j in self.local}
         if cached is None:
+            hook(self)
             return 0
-        if cached[0] == "rows" and (inplace_supported(eng.params, cached[4]) or single_group_inplace(eng.params, cached[3])):
-            # one slab: the reduce reads every row once and overwrites the destinations in place (no second slab,
-            # no copy back into the slab the captured graphs point at; uncovered rows keep their model by themselves)
-            _, send_lists, recv_lists, plan, n_recv = cached
+        if cached[0] == "rows":
+            _, send_lists, recv_lists, plan, n_recv = cached[:5]
             got = self._exchange_rows(send_lists, recv_lists, n_recv)
-            if run_plan_inplace(eng.params, self.staging, plan, n_recv):
-                return got
-            raise RuntimeError("in-place FedAvg declined a plan it had accepted")
+            hook(self)
+            if inplace_supported(eng.params, n_recv) or single_group_inplace(eng.params, plan):
+                # one slab: the reduce reads every row once and overwrites the destinations in place (no second slab,
+                # no copy back into the slab the captured graphs point at; uncovered rows keep their model by themselves)
+                if run_plan_inplace(eng.params, self.staging, plan, n_recv):
+                    return got
+                raise RuntimeError("in-place FedAvg declined a plan it had accepted")
+            out = eng.alt_slab()
+            if not all_covered:
+                out.copy_(eng.params)        # rows nobody writes (dead / isolated nodes) keep their model
+            run_plan(eng.params, self.staging, out, plan)
+            eng.swap_slabs()
+            return got
+        hook(self)
         out = eng.alt_slab()
         if not all_covered:
-            out.copy_(eng.params)        # rows nobody writes (dead / isolated nodes) keep their model
+            out.copy_(eng.params)
         return self._run_exchange(cached, out)
 
     def _aggregate_virtual_devices(self) -> int:
@@ -372,27 +426,22 @@ class BatchedFederation:
         return entry[:2]
 
     def _run_exchange(self, cached, out) -> int:
+        """The all-reduce form of the exchange (every aggregator shares one train set)."""
         eng = self.engine
-        if cached[0] == "allreduce":
-            plan, idx = cached[4], cached[5]       # device-side plan / destination rows, built once per structure
-            P = eng.layout.row_stride
-            if self._partial is None or self._partial.shape[1] != P:
-                self._partial = torch.zeros(1, P, device=self.device)
-            partial = self._partial
-            if plan is not None:
-                run_plan(eng.params, None, partial, plan)      # (the reduce kernel overwrites its destination rows)
-            else:
-                partial.zero_()
-            partial = self.comm.allreduce_partial(partial)
-            if idx is not None:
-                out[idx] = partial.expand(idx.numel(), -1)
-            eng.swap_slabs()
-            return self.world - 1
-        _, send_lists, recv_lists, plan, n_recv = cached
-        got = self._exchange_rows(send_lists, recv_lists, n_recv)
-        run_plan(eng.params, self.staging, out, plan)
+        plan, idx = cached[4], cached[5]       # device-side plan / destination rows, built once per structure
+        P = eng.layout.row_stride
+        if self._partial is None or self._partial.shape[1] != P:
+            self._partial = torch.zeros(1, P, device=self.device)
+        partial = self._partial
+        if plan is not None:
+            run_plan(eng.params, None, partial, plan)      # (the reduce kernel overwrites its destination rows)
+        else:
+            partial.zero_()
+        partial = self.comm.allreduce_partial(partial)
+        if idx is not None:
+            out[idx] = partial.expand(idx.numel(), -1)
         eng.swap_slabs()
-        return got
+        return self.world - 1
 
     def _transfer_leadership(self) -> None:
         """SDFL: the aggregator hands its role to a random live neighbour (node.py:676-686)."""
@@ -435,8 +484,6 @@ class BatchedFederation:
             torch.cuda.nvtx.range_pop()
         t = tick("train", t)
         self._apply_faults("mid")             # nodes that die now have trained, but their model never arrives
-        if self.pre_aggregate_hook is not None:
-            self.pre_aggregate_hook(self)
         pushed = self._range("exchange+aggregate")
         got = self.aggregate()
         if pushed:
@@ -453,8 +500,9 @@ class BatchedFederation:
         for i in timed_out:
             self.membership.note("aggregation_timeout", i)
         if not self.external_clock:
-            self.membership.advance(max(time.perf_counter() - t0, self.membership.period)
-                                    + (self.aggregation_timeout if timed_out else 0.0))
+            # (several ranks: one heartbeat period per round whatever the wall time, so every rank's table moves alike)
+            wall = self.membership.period if self.world > 1 else max(time.perf_counter() - t0, self.membership.period)
+            self.membership.advance(wall + (self.aggregation_timeout if timed_out else 0.0))
         self._sync_membership()
         n_train = eng.train_x.shape[1]
         rep = RoundReport(self.round, time.perf_counter() - t0, phases,

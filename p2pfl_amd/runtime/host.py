@@ -67,16 +67,18 @@ class CommandBus:
 
     def __init__(self):
         self._q: "collections.deque" = collections.deque()
-        self._subs: List[Callable[[int, bytes], None]] = []
+        self._subs: List[tuple] = []
         self._lock = threading.Lock()
         self.counts: "collections.Counter" = collections.Counter()     # header -> messages published
 
-    def subscribe(self, fn: Callable[[int, bytes], None]) -> None:
-        self._subs.append(fn)
+    def subscribe(self, fn: Callable[[int, bytes], None], local_only: bool = False) -> None:
+        """``local_only``: not for messages that came in from another rank's bus (what forwards to the ranks)."""
+        self._subs.append((fn, local_only))
 
-    def publish(self, sender: int, msg: bytes) -> None:
+    def publish(self, sender: int, msg: bytes, remote: bool = False) -> None:
+        """``remote``: the message was published on another rank's bus and arrived over the rank bridge."""
         with self._lock:
-            self._q.append((sender, msg))
+            self._q.append((sender, msg, remote))
             self.counts[msg.split(b" ", 1)[0].strip().decode(errors="replace")] += 1
 
     def pump(self) -> int:
@@ -85,8 +87,10 @@ class CommandBus:
             with self._lock:
                 if not self._q:
                     return n
-                sender, msg = self._q.popleft()
-            for fn in list(self._subs):
+                sender, msg, remote = self._q.popleft()
+            for fn, local_only in list(self._subs):
+                if remote and local_only:
+                    continue
                 try:
                     fn(sender, msg)
                 except Exception as e:        # a faulty observer must not stop the control plane
@@ -169,6 +173,10 @@ class VirtualNode:
     def get_network_nodes(self) -> List[str]:
         return self._host.network_nodes()
 
+    def is_local(self) -> bool:
+        """Does THIS rank host the node's row (model access and gateways need that; everything else works anywhere)?"""
+        return self.idx in self._host.fed.local
+
     def connect_to(self, h, p, full=False, force=False):
         """Peer with an external TCP node (through this node's gateway endpoint, created on demand)."""
         return self._host.gateway(self.idx).connect_to(h, p, full, force)
@@ -182,6 +190,9 @@ class VirtualNode:
 
     # model access (learner-style)
     def get_parameters(self) -> "OrderedDict[str, torch.Tensor]":
+        if not self.is_local():
+            raise LookupError(f"node {self.idx} lives on rank {int(self._host.fed.owner[self.idx])}, not on rank "
+                              f"{self._host.fed.rank}: ask that rank's host for its parameters")
         return self._host.fed.engine.get_state_dict(self.idx - self._host.fed.local.start)
 
     def get_num_samples(self):
@@ -345,7 +356,16 @@ class GatewayNode(Node):
 # the host
 # ======================================================================================================
 class FederationHost:
-    """Control plane of one :class:`BatchedFederation` (single process; one rank)."""
+    """Control plane of one :class:`BatchedFederation` - one host per RANK for the nodes that rank hosts.
+
+    Several ranks (one process per GPU): every host beats, reports and serves gateways for ITS nodes; the hosts are
+    joined by a :class:`~p2pfl_amd.runtime.bridge.RankBridge` (TCP between the rank hosts, never the RCCL stream) that
+    carries each bus message to the other ranks' buses - so a gateway on any rank floods the BEAT / ROLE of all N nodes
+    to its TCP peers (heartbeater.py:66-139) - and START / STOP_LEARNING to every rank's learning loop
+    (node.py:224-271). The loops run the collective exchange in lock step, so what must be identical on all ranks is
+    AGREED at the top of every round over the job's host-side gloo group: the stop flag (all ranks leave the loop at
+    the same round) and the set of gateway nodes (a gateway's rank needs the ROWS of its train set, so the exchange
+    must not collapse into an all-reduce; its aggregate goes back to adopting nodes on other ranks by a broadcast)."""
 
     def __init__(self, fed: BatchedFederation, names: Optional[List[str]] = None, scenario: str = "scenario",
                  participant: Optional[dict] = None, tick: float = 0.05, status_poster: Optional[Callable] = None):
@@ -377,6 +397,17 @@ class FederationHost:
         self._service: Optional[threading.Thread] = None
         self._beats = np.zeros(fed.N, dtype=np.int64)
         self._last_tick = None
+        self.rank, self.world = fed.rank, fed.world
+        self._init_src: Optional[int] = None           # rank whose gateway received an external initiator's model
+        self._gw_mask = np.zeros(fed.N, dtype=np.uint8)  # gateway nodes of the WHOLE job (agreed per round)
+        self.bridge = None
+        if fed.world > 1:
+            from .bridge import RankBridge
+            group = fed.ensure_host_group()             # collective: every rank builds its host at the same point
+            if group is None:
+                raise ValueError("a multi-rank FederationHost needs the federation's process group")
+            self.bridge = RankBridge(fed.rank, fed.world, group, self._on_bridge_frame)
+            self.bus.subscribe(self._forward_to_ranks, local_only=True)
         fed.external_clock = True
         fed.membership.period = self.heartbeat_period
         fed.membership.timeout = self.node_timeout
@@ -384,7 +415,7 @@ class FederationHost:
         fed.pre_aggregate_hook = self._pre_aggregate
         fed.post_aggregate_hook = self._post_aggregate
         self.bus.subscribe(self._forward_to_gateways)
-        for i in range(fed.N):                          # stagger the heartbeats over one period
+        for i in fed.local:                             # this rank's nodes; staggered over one period
             self.wheel.schedule(self.heartbeat_period * (i + 1) / fed.N, lambda i=i: self._beat(i), self.heartbeat_period)
 
     # ------------------------------------------------------------------ service thread
@@ -418,6 +449,8 @@ class FederationHost:
             gw.stop()
         if self._learning_thread is not None:
             self._learning_thread.join(timeout=10)
+        if self.bridge is not None:
+            self.bridge.close()
 
     def _serve(self) -> None:
         while not self._terminate.is_set():
@@ -469,6 +502,33 @@ class FederationHost:
             if sender != vidx:                          # the gateway's own Node sends its own beats
                 gw.broadcast(msg)
 
+    # ------------------------------------------------------------------ other ranks (host-side bridge)
+    def _forward_to_ranks(self, sender: int, msg: bytes) -> None:
+        """Every message published on THIS rank's bus also appears on the other ranks' buses."""
+        from .bridge import BUS
+        self.bridge.send_all(BUS, sender, msg)
+
+    def _on_bridge_frame(self, src_rank: int, kind: int, sender: int, payload: bytes) -> None:
+        """A frame of another rank's host (bridge reader thread)."""
+        from . import bridge as B
+        if kind == B.BUS:
+            if payload.startswith(b"BEAT") and 0 <= sender < self.fed.N:
+                m = self.fed.membership
+                m.last_beat[sender] = max(m.last_beat[sender], m.clock)
+            self.bus.publish(sender, payload, remote=True)
+        elif kind == B.START:
+            d = json.loads(payload.decode())
+            self._remote_start(int(d["rounds"]), int(d["epochs"]), int(d["init_src"]))
+        elif kind == B.STOP:
+            self._local_stop(via=-1)
+        elif kind == B.NAME:
+            if 0 <= sender < self.fed.N:
+                self.names[sender] = payload.decode()
+        elif kind == B.XBEAT:
+            name = payload.decode()
+            if name not in self.names:
+                self.external[name] = time.time()
+
     # ------------------------------------------------------------------ membership views
     def network_nodes(self) -> List[str]:
         live = [self.names[i] for i in np.nonzero(self.fed.membership.believed())[0]]
@@ -477,6 +537,9 @@ class FederationHost:
     def on_external_beat(self, name: str) -> None:
         if name not in self.names:
             self.external[name] = time.time()
+            if self.bridge is not None:
+                from .bridge import XBEAT
+                self.bridge.send_all(XBEAT, -1, name.encode())
 
     def virtual_train_set_names(self, i: int) -> List[str]:
         return [self.names[j] for j in self.fed.train_set(i) if j != i]
@@ -489,6 +552,9 @@ class FederationHost:
             gw = self.gateways.get(vidx)
             if gw is not None:
                 return gw
+            if vidx not in self.fed.local:
+                raise ValueError(f"virtual node {vidx} is hosted by rank {int(self.fed.owner[vidx])}: its TCP gateway "
+                                 f"is opened by that rank's host, not by rank {self.rank}")
             if port is None:
                 port = int(self.names[vidx].rsplit(":", 1)[1])
             p = json.loads(json.dumps(self.participant))
@@ -499,6 +565,10 @@ class FederationHost:
             self.names[vidx] = gw.get_name()
             gw.start()
             self.gateways[vidx] = gw
+            self._gw_mask[vidx] = 1
+            if self.bridge is not None:
+                from .bridge import NAME
+                self.bridge.send_all(NAME, vidx, self.names[vidx].encode())
             return gw
 
     def on_gateway_parameters(self, vidx: int, sd) -> None:
@@ -512,31 +582,43 @@ class FederationHost:
             self._init_ready.set()
 
     def virtual_partial(self, g: int):
-        """(state_dict, contributor names, weight) of the co-resident part of g's train set without g itself - the
-        partial aggregate a neighbour would gossip (aggregator.py:181-208), computed by the reduce kernel."""
+        """(state_dict, contributor names, weight) of the virtual part of g's train set without g itself - the partial
+        aggregate a neighbour would gossip (aggregator.py:181-208), computed by the reduce kernel over this rank's rows
+        and the rows of other ranks that the round's exchange has staged (``fed.aggregate`` runs the exchange before it
+        releases the gateways)."""
         fed = self.fed
         members = [j for j in fed.train_set(g) if j != g and fed._present(j)
                    and fed.roles[j] not in (Role.PROXY, Role.IDLE) and (Role.trains(fed.roles[j]) or Role.aggregates(fed.roles[j]))]
+        lo = fed.local.start
+        row_of = fed._row_of or {j: j - lo for j in fed.local}
+        missing = [j for j in members if j not in row_of]
+        if missing:
+            # (a gateway opened in the middle of a round, or one whose node does not aggregate: the exchange of this
+            # round did not stage those rows)
+            logging.warning("[HOST] gateway %d: rows of %s are not on rank %d this round; partial aggregate without them",
+                            g, missing, self.rank)
+            members = [j for j in members if j in row_of]
         if not members:
             return None
-        lo = fed.local.start
         eng = fed.engine
         out = torch.zeros(1, eng.layout.row_stride, device=eng.params.device)
-        plan = build_plan([([j - lo for j in members], [float(fed.weights[j]) for j in members], [0])])
-        run_plan(eng.params, None, out, plan)
+        plan = build_plan([([row_of[j] for j in members], [float(fed.weights[j]) for j in members], [0])])
+        run_plan(eng.params, fed.staging, out, plan)
         sd = OrderedDict((k, v.detach().cpu()) for k, v in eng.layout.row_to_state_dict(out[0]).items())
         return sd, [self.names[j] for j in members], int(sum(fed.weights[j] for j in members))
 
     # ------------------------------------------------------------------ learning control
     def start_learning(self, rounds: int, epochs: int, initiator: Optional[int] = None) -> None:
         """``Node.set_start_learning`` of a virtual node (node.py:224-257): START_LEARNING goes out on the bus and,
-        through the gateways, to external peers, which also receive the initial model from them."""
+        through the gateways, to external peers, which also receive the initial model from them. The learning loops
+        of ALL ranks start (bridge)."""
         with self._lock:
             if self.round is not None:
                 logging.info("[HOST] Learning already started")
                 return
+            self._init_src = None
             self._begin(rounds, epochs)
-        self.bus.publish(initiator or 0, CommunicationProtocol.build_start_learning_msg(rounds, epochs))
+        self._announce_start(rounds, epochs, initiator or 0, -1)
         for gw in self.gateways.values():
             if gw.round is None:
                 gw.set_start_learning(rounds, epochs)
@@ -547,11 +629,34 @@ class FederationHost:
             if self.round is not None:
                 return
             self._init_ready.clear()                    # wait for the initiator's weights (on_gateway_parameters)
+            self._init_src = self.rank if self.world > 1 else None
             self._begin(rounds, epochs)
-        self.bus.publish(via, CommunicationProtocol.build_start_learning_msg(rounds, epochs))
+        self._announce_start(rounds, epochs, via, self.rank)
         for vidx, gw in self.gateways.items():
             if vidx != via and gw.round is None:
                 gw._start_learning_thread(rounds, epochs)
+
+    def _announce_start(self, rounds: int, epochs: int, sender: int, init_src: int) -> None:
+        self.bus.publish(sender, CommunicationProtocol.build_start_learning_msg(rounds, epochs))
+        if self.bridge is not None:
+            from .bridge import START
+            self.bridge.send_all(START, sender, json.dumps({"rounds": rounds, "epochs": epochs,
+                                                            "init_src": init_src}).encode())
+
+    def _remote_start(self, rounds: int, epochs: int, init_src: int) -> None:
+        """Another rank's host started learning (a virtual node there, or an external initiator at one of its
+        gateways whose model that rank will broadcast: ``init_src``)."""
+        with self._lock:
+            if self.round is not None:
+                return
+            self._init_src = init_src if init_src >= 0 else None
+            self._begin(rounds, epochs)
+        for gw in self.gateways.values():
+            if gw.round is None:
+                if init_src < 0:
+                    gw.set_start_learning(rounds, epochs)       # its TCP peers get START_LEARNING + the initial model
+                else:
+                    gw._start_learning_thread(rounds, epochs)
 
     def _begin(self, rounds: int, epochs: int) -> None:
         self.round, self.totalrounds, self.epochs = 0, int(rounds), int(epochs)
@@ -561,11 +666,15 @@ class FederationHost:
         self._learning_thread.start()
 
     def stop_learning(self) -> None:
-        """``Node.set_stop_learning`` of a virtual node: the run ends after the round in flight."""
+        """``Node.set_stop_learning`` of a virtual node: the run ends after the round in flight - on every rank (the
+        loops agree on the stop flag at the top of each round)."""
         if self.round is None:
             return
         self._stop.set()
         self.bus.publish(0, CommunicationProtocol.build_stop_learning_msg())
+        if self.bridge is not None:
+            from .bridge import STOP
+            self.bridge.send_all(STOP, -1)
         for gw in self.gateways.values():
             if gw.round is not None:
                 gw.set_stop_learning()
@@ -573,13 +682,41 @@ class FederationHost:
     def on_external_stop(self, via: int) -> None:
         if self.round is None:
             return
+        if self.bridge is not None:
+            from .bridge import STOP
+            self.bridge.send_all(STOP, via)
+        self._local_stop(via)
+
+    def _local_stop(self, via: int) -> None:
+        """STOP_LEARNING that did not originate at one of this host's virtual nodes (a TCP peer of gateway ``via``,
+        another rank, or the ranks' agreement at the top of a round)."""
+        if self.round is None or self._stop.is_set():
+            return
         self._stop.set()
         self._init_ready.set()
-        self.bus.publish(via, CommunicationProtocol.build_stop_learning_msg())
+        self.bus.publish(max(via, 0), CommunicationProtocol.build_stop_learning_msg(), remote=via < 0)
         for vidx, gw in self.gateways.items():
             gw.learner.interrupt_fit()
             if vidx != via and gw.round is not None:
                 gw.set_stop_learning()
+
+    def _agree(self) -> bool:
+        """Top of a round, all ranks in lock step: OR of the stop flags and of the gateway masks over the job's
+        host-side group. Returns the agreed stop flag."""
+        fed = self.fed
+        if self.world == 1:
+            return self._stop.is_set()
+        import torch.distributed as dist
+        t = torch.zeros(1 + fed.N, dtype=torch.uint8)
+        t[0] = 1 if self._stop.is_set() else 0
+        t[1:] = torch.from_numpy(self._gw_mask)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=fed.host_pg)
+        self._gw_mask = t[1:].numpy().copy()
+        fed.allow_allreduce = not bool(self._gw_mask.any())
+        stop = bool(t[0])
+        if stop and not self._stop.is_set():
+            self._local_stop(via=-1)
+        return stop
 
     # ------------------------------------------------------------------ the learning thread
     def _learn(self) -> None:
@@ -587,8 +724,18 @@ class FederationHost:
         try:
             if not self._init_ready.wait(self.aggregation_timeout * 4):
                 logging.error("[HOST] the initial model never arrived")
+            if self.world > 1 and self._init_src is not None:
+                # an external initiator's model reached ONE rank's gateway: its row goes to every rank (the same
+                # init-model diffusion, node.py:298-299,702-724, as one broadcast)
+                eng = fed.engine
+                row = eng.params[0].clone()
+                fed.comm.broadcast(row, self._init_src)
+                if self.rank != self._init_src:
+                    eng.params.copy_(row.unsqueeze(0).expand(eng.K, -1))
             first = fed.round
-            while not self._stop.is_set() and self.round is not None and self.round < self.totalrounds:
+            while self.round is not None and self.round < self.totalrounds:
+                if self._agree():
+                    break
                 rep = fed.run_round()
                 self.reports.append(rep)
                 if self.round_callback is not None:
@@ -634,18 +781,34 @@ class FederationHost:
                 time.sleep(0.005)
 
     def _post_aggregate(self, fed: BatchedFederation) -> None:
-        if not self.gateways:
+        gws = sorted(int(i) for i in np.nonzero(self._gw_mask)[0]) if self.world > 1 else sorted(self.gateways)
+        if not gws:
             return
         eng = fed.engine
         lo = fed.local.start
         _, adopt = fed._round_structure()
-        for vidx, gw in self.gateways.items():
-            if not fed._present(vidx) or gw.learner._sd is None:
+        for vidx in gws:
+            if not fed._present(vidx):
                 continue
-            row = torch.zeros(eng.layout.row_stride)
-            eng.layout.state_dict_to_row(gw.learner._sd, row)
-            row = row.to(eng.params.device)
-            eng.params[vidx - lo].copy_(row)
-            for w, a in adopt.items():                  # co-resident waiting nodes that take the gateway's result
-                if a == vidx and w in fed.local:
-                    eng.params[w - lo].copy_(row)
+            owner = int(fed.owner[vidx])
+            takers = [w for w, a in adopt.items() if a == vidx]
+            if owner == self.rank:
+                gw = self.gateways.get(vidx)
+                if gw is not None and gw.learner._sd is not None:
+                    row = torch.zeros(eng.layout.row_stride)
+                    eng.layout.state_dict_to_row(gw.learner._sd, row)
+                    row = row.to(eng.params.device)
+                    eng.params[vidx - lo].copy_(row)
+                    for w in takers:                    # co-resident waiting nodes that take the gateway's result
+                        if w in fed.local:
+                            eng.params[w - lo].copy_(row)
+            if self.world > 1 and any(int(fed.owner[w]) != owner for w in takers):
+                # waiting nodes on OTHER ranks adopt the gateway's aggregate too (it holds the external models their own
+                # rank never saw): one broadcast of the row from the gateway's rank; every rank derives the same
+                # ``adopt`` map, so all of them take part
+                row = eng.params[vidx - lo].clone() if owner == self.rank else torch.empty_like(eng.params[0])
+                fed.comm.broadcast(row, owner)
+                if owner != self.rank:
+                    for w in takers:
+                        if w in fed.local:
+                            eng.params[w - lo].copy_(row)

@@ -94,11 +94,12 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
                  gateways=(), wait_start: float = None, placement: str = None) -> dict:
     """Run the scenario of ``config_dir`` on this rank's GPU.
 
-    ``control_plane`` (one rank): the co-resident nodes get the reference's protocol behaviour from a
-    :class:`~p2pfl_amd.runtime.host.FederationHost` - BEAT / ROLE / MODELS_READY on an in-process bus, status POSTs
-    per node, and for every ``gateways`` entry (``IDX[:PORT]``) a TCP endpoint through which reference-protocol
-    ``Node`` processes peer with virtual node IDX. ``wait_start`` (seconds): do not start by ourselves, wait that
-    long for a START_LEARNING from such a peer (fedstellar/node.py:224-271).
+    ``control_plane``: the co-resident nodes get the reference's protocol behaviour from a
+    :class:`~p2pfl_amd.runtime.host.FederationHost` per rank - BEAT / ROLE / MODELS_READY on an in-process bus (joined
+    across ranks by the host-side bridge), status POSTs per node, and for every ``gateways`` entry (``IDX[:PORT]``) a
+    TCP endpoint - on the rank that hosts node IDX - through which reference-protocol ``Node`` processes peer with
+    virtual node IDX. ``wait_start`` (seconds): do not start by ourselves, wait that long for a START_LEARNING from
+    such a peer (fedstellar/node.py:224-271); whichever rank receives it starts all of them.
     """
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -156,7 +157,8 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
                             aggregation_timeout=float(p0.get("AGGREGATION_TIMEOUT", 60)),
                             # the reference's failure semantics: a dead node is waited for (AGGREGATION_TIMEOUT, on
                             # the virtual clock) until the heartbeat table evicts it NODE_TIMEOUT later
-                            instant_detection=False, virtual_devices=virtual_devices, block_sizes=block_sizes)
+                            instant_detection=False, virtual_devices=virtual_devices, block_sizes=block_sizes,
+                            log_steps=True)
     for f in load_faults(config_dir, parts):
         fed.schedule_fault(int(f["round"]), f["action"], pos[int(f["node"])],
                            None if f.get("peer") is None else pos[int(f["peer"])], f.get("phase", "start"))
@@ -243,8 +245,23 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
         total_samples += rep.train_samples
         test = fed.engine.stats["Test"].summary()
         train = fed.engine.stats["Train"].summary()
+        # the reference's per-step series (Train/Loss + macro metrics of the step's batch every 20 optimizer steps,
+        # lightninglearner.py:188, mnist/models/mlp.py:33-106) on the global step axis, from the snapshots the HIP
+        # engine takes inside its captured graph
+        per_loss = fed.engine.step_losses() if hasattr(fed.engine, "step_losses") else None
+        if per_loss is not None:
+            per_cm = fed.engine.step_metrics()
+            base = r * per_loss.shape[0]
+            for t in sorted(per_cm):
+                for k, i in enumerate(fed.local):
+                    if fed.alive[i]:
+                        row = {"Train/Loss": float(per_loss[t - 1, k])}
+                        row.update({f"Train/{name}": v for name, v in per_cm[t][k].items()})
+                        loggers[i].log_metrics_direct(row, base + t)
         for k, i in enumerate(fed.local):
-            m = {"Round": r, "Test/Loss": float(test["loss"][k]), "Train/Loss": float(train["loss"][k]),
+            # (with the per-step series above, "Train/Loss" is the step axis; the epoch mean goes to TrainEpoch/Loss)
+            m = {"Round": r, "Test/Loss": float(test["loss"][k]),
+                 ("TrainEpoch/Loss" if per_loss is not None else "Train/Loss"): float(train["loss"][k]),
                  "Federation/RoundSeconds": rep.seconds, "Federation/ExchangedRows": rep.exchanged_rows,
                  "Federation/AggregationTimeouts": rep.timeouts, "Federation/EncryptedBytes": rep.encrypted_bytes}
             for ph, sec in rep.phase_seconds.items():
@@ -260,9 +277,7 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
                 post_status(i)
 
     if control_plane or gateways:
-        if world > 1:
-            raise ValueError("--control-plane hosts one rank: run it with one process (the other ranks' nodes are "
-                             "reached through the collective exchange, not the command bus)")
+        # one host per rank for the nodes that rank hosts; the hosts are joined by the rank bridge (runtime/bridge.py)
         from .host import FederationHost
         names = [f"{p['network_args']['ip']}:{p['network_args']['port']}" for p in parts]
         host = FederationHost(fed, names=names, scenario=scenario, participant=p0,
@@ -272,15 +287,17 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
         for g in gateways:
             vidx, gh, gp = _parse_gateway(g)
             vidx = pos[vidx]
+            if vidx not in fed.local:
+                continue                                  # the rank that hosts the node opens its gateway
             gw = host.gateway(vidx, gh or parts[vidx]["network_args"]["ip"], gp)
             node_log(vidx, f"TCP gateway of virtual node {ext[vidx]} listening on {gw.get_name()}")
         if wait_start is not None:
             if not host.wait_started(wait_start):
                 logging.warning("no START_LEARNING within %.0f s: starting locally", wait_start)
                 host.start_learning(rounds, epochs)
-        else:
-            host.start_learning(rounds, epochs)
-        host.wait_started(30)
+        elif rank == 0:
+            host.start_learning(rounds, epochs)          # (the bridge starts the other ranks' loops)
+        host.wait_started(30 if wait_start is None else wait_start + 30)
         host.wait_finished()
         host.stop()
         rounds = done[0]
@@ -325,7 +342,8 @@ def main(argv=None):
     ap.add_argument("--resume", default=None, help="directory with participant_<i>_final.ckpt files to start from")
     ap.add_argument("--control-plane", action="store_true",
                     help="serve the reference's node protocol for the co-resident nodes (heartbeats, roles, "
-                         "MODELS_READY, status POSTs; START/STOP_LEARNING honoured) - one rank")
+                         "MODELS_READY, status POSTs; START/STOP_LEARNING honoured) - one host per rank, joined by a "
+                         "host-side TCP bridge")
     ap.add_argument("--gateway", action="append", default=[], metavar="IDX[:PORT]",
                     help="open a TCP endpoint for virtual node IDX so reference-protocol nodes can peer with it "
                          "(implies --control-plane; repeatable)")

@@ -62,7 +62,8 @@ def test_two_engine_learners_in_threads_share_the_gpu():
 
 def test_engine_learner_aliases_the_slab_and_logs_every_20_steps():
     """K=1 learner hygiene: the model's parameters are views of slab row 0 (no host hop per fit / evaluate) and
-    Train/Loss is reported every 20 optimizer steps from a table the captured graph fills."""
+    Train/{Loss,Accuracy,Precision,Recall,F1Score} of the step's batch are reported every 20 optimizer steps (the
+    reference's per-step series, mnist/models/mlp.py:33-106) from tables the captured graph fills."""
     class Rec:
         def __init__(self):
             self.rows, self.global_step = [], 0
@@ -76,10 +77,13 @@ def test_engine_learner_aliases_the_slab_and_logs_every_20_steps():
     eng = ln._engine
     for name, p in ln.model.named_parameters():
         assert p.is_cuda and p.data_ptr() == eng.layout.view(eng.params, name)[0].data_ptr()
-    steps = [s for s, m in ln.logger.rows if set(m) == {"Train/Loss"}]
-    assert steps == [20, 40, 60]
-    losses = [m["Train/Loss"] for s, m in ln.logger.rows if set(m) == {"Train/Loss"}]
+    per_step = {"Train/Loss", "Train/Accuracy", "Train/Precision", "Train/Recall", "Train/F1Score"}
+    rows = [(s, m) for s, m in ln.logger.rows if set(m) == per_step]
+    assert [s for s, _ in rows] == [20, 40, 60]
+    losses = [m["Train/Loss"] for _, m in rows]
     assert all(0 < l < 5 for l in losses) and losses[-1] < losses[0]
+    assert all(0.0 <= m[k] <= 1.0 for _, m in rows for k in per_step - {"Train/Loss"})
+    assert rows[-1][1]["Train/Accuracy"] > rows[0][1]["Train/Accuracy"]      # a batch at step 60 beats one at step 20
     # a payload from the wire (host tensors) lands in the slab row through load_state_dict, aliasing intact
     sd = {k: torch.full_like(v, 0.25).cpu() for k, v in ln.get_parameters().items()}
     ln.set_parameters(sd)

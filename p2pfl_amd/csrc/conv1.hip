@@ -334,7 +334,10 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1WgradArgs a) {
 
 // Sum of the per-wave partial tiles of one client, partial by partial in index order, then either the gradient store or
 // the layer's optimizer step (the gradient value is final here, so it never has to reach memory).
-// One block per client, thread = (accumulator register e, lane) of the MFMA tile layout.
+// A block owns a quarter of one 32 x 32 tile (jn) of one client, thread = (accumulator register e, lane) of the MFMA
+// tile layout: 4 * njn blocks per client - one 1024-thread block per client left 10-client shards with 10 blocks, each
+// walking up to 128 partials one dependent load after the other (87 us per step on the critical chain). The loads of 8
+// partials are in flight together; the ADDS stay in index order, so the sum is bit-equal to the one-by-one loop.
 struct Conv1FinishArgs {
     const float* part; int nparts, njn, tap8;
     float* dw; long dw_cs; float* db; long db_cs;
@@ -342,32 +345,41 @@ struct Conv1FinishArgs {
     OptEpi opt;
 };
 
-__global__ __launch_bounds__(1024) void conv1_wgrad_finish_kernel(Conv1FinishArgs a) {
-    const int c = blockIdx.x, lane = threadIdx.x & 63, e = threadIdx.x >> 6;
+__global__ __launch_bounds__(256) void conv1_wgrad_finish_kernel(Conv1FinishArgs a) {
+    const int c = blockIdx.x, jn = blockIdx.y >> 2;
+    const int t = (blockIdx.y & 3) * 256 + threadIdx.x;           // index into the 1024-float tile
+    const int lane = t & 63, e = t >> 6;
     const int f = mfma_row(e, lane), T = a.KS * a.KS;
     const OptEpi::Scal sc = a.opt.kind ? a.opt.scal() : OptEpi::Scal{0.f, 0.f};
-    const float* p = a.part + (size_t)c * a.nparts * a.njn * 1024 + threadIdx.x;
-    for (int jn = 0; jn < a.njn; ++jn) {
-        float s = 0.f;
-        for (int k = 0; k < a.nparts; ++k) s += p[((size_t)k * a.njn + jn) * 1024];
-        if (f >= a.F) continue;
-        const int n = jn * 32 + (lane & 31);
-        int tap = -1; bool bias = false;
-        if (a.tap8) {
-            const int ky = n >> 3, kx = n & 7;
-            if (n == 63) bias = true;
-            else if (ky < a.KS && kx < a.KS) tap = ky * a.KS + kx;
-        } else {
-            if (n == T) bias = true;
-            else if (n < T) tap = n;
-        }
-        if (bias) {
-            if (a.opt.kind) a.opt.bias(sc, c, f, s);
-            else a.db[c * a.db_cs + f] = s;
-        } else if (tap >= 0) {
-            if (a.opt.kind) a.opt.weight(sc, c, f * T + tap, s);
-            else a.dw[c * a.dw_cs + f * T + tap] = s;
-        }
+    const float* p = a.part + ((size_t)c * a.nparts * a.njn + jn) * 1024 + t;
+    const size_t ks = (size_t)a.njn * 1024;
+    float s = 0.f;
+    int k = 0;
+    for (; k + 8 <= a.nparts; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * ks];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < a.nparts; ++k) s += p[(size_t)k * ks];
+    if (f >= a.F) return;
+    const int n = jn * 32 + (lane & 31);
+    int tap = -1; bool bias = false;
+    if (a.tap8) {
+        const int ky = n >> 3, kx = n & 7;
+        if (n == 63) bias = true;
+        else if (ky < a.KS && kx < a.KS) tap = ky * a.KS + kx;
+    } else {
+        if (n == T) bias = true;
+        else if (n < T) tap = n;
+    }
+    if (bias) {
+        if (a.opt.kind) a.opt.bias(sc, c, f, s);
+        else a.db[c * a.db_cs + f] = s;
+    } else if (tap >= 0) {
+        if (a.opt.kind) a.opt.weight(sc, c, f * T + tap, s);
+        else a.dw[c * a.dw_cs + f * T + tap] = s;
     }
 }
 
@@ -401,7 +413,8 @@ int conv1_wgrad_finish(const float* part, int nparts, int njn, int tap8, float* 
     if (!opt_epi_valid(opt)) return -1;
     Conv1FinishArgs a{part, nparts, njn, tap8, dw, dw_cs, db, db_cs, F, KS, make_opt_epi(opt)};
     if (a.opt.kind == 0 && (dw == nullptr || db == nullptr)) return -1;
-    hipLaunchKernelGGL(conv1_wgrad_finish_kernel, dim3(K), dim3(1024), 0, stream, a);
+    if (K > 65535 || njn < 1) return -1;
+    hipLaunchKernelGGL(conv1_wgrad_finish_kernel, dim3(K, 4 * njn), dim3(256), 0, stream, a);
     P2PFL_RETURN_LAST_ERROR();
 }
 

@@ -15,8 +15,14 @@
 //   dgrad: image = pooled gradient routed to the arg-max pixel while staging (75 % zeros are never
 //          read from HBM), M = natural pixels of one sample, N = C_in, taps mirrored.
 //
-// LDS strides are padded so ds_read_b128 lane groups spread over the 16 slots of the 256-B bank row
-// (searched offline: fwd 1.6x, dgrad 1.07x average conflict factor; LDS has 2x headroom here).
+// LDS layout of the 64-B-pixel images (forward, split data gradient): ds_read_b128 serves a wave in four 16-lane
+// groups over the 16 slots (16 B) of the 256-B bank row. The row stride is 128 mod 256 bytes and the four 16-byte
+// channel chunks of a pixel are ROTATED by a function of the pixel position, chosen per kernel so that the 16 lanes of
+// every group hit 16 different slots for every tap (tools/probe/lds_conflict_sim.py: 4.0 cycles per read, was 6.6
+// forward / 8.3 split data gradient with the padded strides; SQ_LDS_BANK_CONFLICT 29 % / 48 % of the LDS cycles):
+//   forward : a row tile = the 7 pool windows of ONE window row, windows placed on the 8 four-lane slots so that each
+//             lane group holds window columns 0-3 or 4-6 (distinct mod 4); chunk rotation = (X >> 1)
+//   dgrad   : natural pixel order; chunk rotation = ((14 Y + X) >> 2)  (= (p + tap offset) >> 2 for output pixel p)
 // Blocks of one client are mapped to one XCD so its weights stay in that XCD's L2.
 //
 // Reference layers: fedstellar/learning/pytorch/mnist/models/cnn.py:138-142,152-154 and
@@ -40,9 +46,9 @@ struct Geo {
     static constexpr int PAD = KS / 2;
     static constexpr int IW = P1 + 2 * PAD;
     static constexpr int T = KS * KS;
-    // forward image: 64 B / pixel
-    static constexpr int XRS = IW * 64 + 16;
-    static constexpr int XSS = IW * XRS + (IW == 16 ? 32 : 0);
+    // forward / split-gradient image: 64 B / pixel, row stride = 128 (mod 256)
+    static constexpr int XRS = IW * 64 + (((128 - IW * 64) % 256) + 256) % 256;
+    static constexpr int XSS = IW * XRS;
     // gradient image: 128 B + 16 pad / pixel; row pad makes the 14-pixel row wrap look like +1 pixel
     static constexpr int GPS = 144;
     static constexpr int GRS = IW * GPS + 16 * ((((P1 - IW) * 9) % 16 + 16) % 16);
@@ -118,9 +124,9 @@ __global__ __launch_bounds__(256, 2) void conv2_fwd_kernel(FwdArgs a) {
     using G = Geo<KS>;
     constexpr int S = NS == 1 ? 2 : 1;         // samples per block
     constexpr int NBUF = NS == 1 ? 2 : 1;
-    constexpr int NWIN = S * CELLS2;           // pool windows
-    constexpr int NTILE = (NWIN + 7) / 8;      // row tiles of 8 windows
+    constexpr int NTILE = S * P2;              // row tiles: one window row (7 windows on 8 slots) each
     constexpr int MT = (NTILE + 3) / 4;        // tiles per wave
+    constexpr unsigned SLOT_CX = 0x43261540u;  // window column of slot j (nibble j); slot 7 repeats column 4 (unused)
     constexpr int IMG = S * G::XSS;            // bytes of one term's images
     constexpr int WSL = COUT * 80;             // bytes of one term's weight slice
     constexpr int PLANE = 2 * G::T * COUT * CIN;
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv2_fwd_kernel(FwdArgs a) {
         split_bf16x8<NS>(v, tv);
 #pragma unroll
         for (int e = 0; e < NS; ++e)
-            *reinterpret_cast<bf16x8*>(ximg + e * IMG + s * G::XSS + Y * G::XRS + X * 64 + g * 16) = tv[e];
+            *reinterpret_cast<bf16x8*>(ximg + e * IMG + s * G::XSS + Y * G::XRS + X * 64 + ((g + (X >> 1)) & 3) * 16) = tv[e];
     }
     const __bf16* wf = a.wp + c * a.wp_cs;
 #pragma unroll
@@ -166,14 +172,14 @@ __global__ __launch_bounds__(256, 2) void conv2_fwd_kernel(FwdArgs a) {
     // ---- per-lane image offsets of my row tiles (tiles past the end recompute window 0: an unguarded MFMA
     // loop - a per-tile guard compiles to a branch plus accumulator copies around every MFMA)
     const int ntile = (NTILE - wave + 3) / 4;          // tiles wave, wave+4, ...
+    const int xl = 2 * (int)((SLOT_CX >> (4 * (r >> 2))) & 7u) + (r & 1);     // my pixel column, the same in every tile
     int abase[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        int W = (wave + 4 * i) * 8 + (r >> 2);
-        if (W >= NWIN) W = 0;
-        const int q = r & 3, s = W / CELLS2, cell = W % CELLS2;
-        const int y = 2 * (cell / P2) + (q >> 1), x = 2 * (cell % P2) + (q & 1);
-        abase[i] = s * G::XSS + y * G::XRS + x * 64 + h * 16;
+        int tl = wave + 4 * i;
+        if (tl >= NTILE) tl = 0;
+        const int y = 2 * (tl % P2) + ((r >> 1) & 1);
+        abase[i] = (tl / P2) * G::XSS + y * G::XRS + xl * 64;
     }
     f32x16 acc[MT][2];
 #pragma unroll
@@ -193,9 +199,10 @@ __global__ __launch_bounds__(256, 2) void conv2_fwd_kernel(FwdArgs a) {
                 wnext[e] = *reinterpret_cast<const bf16x8*>(wf + e * PLANE + (t + 1) * COUT * CIN + tid * 8);
         }
         const unsigned char* wb = wbuf[NBUF == 2 ? (t & 1) : 0] + r * 80 + h * 16;
-        const int toff = ky * G::XRS + kx * 64;
+        const int rot = h + ((xl + kx) >> 1);            // chunk rotation of the pixel this lane reads for this tap
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            const int toff = ky * G::XRS + kx * 64 + ((rot + 2 * ks) & 3) * 16;
             bf16x8 bf[NS][2];
 #pragma unroll
             for (int e = 0; e < NS; ++e) {
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv2_fwd_kernel(FwdArgs a) {
                 bf16x8 af[NS];
 #pragma unroll
                 for (int e = 0; e < NS; ++e)
-                    af[e] = *reinterpret_cast<const bf16x8*>(ximg + e * IMG + abase[i] + toff + ks * 32);
+                    af[e] = *reinterpret_cast<const bf16x8*>(ximg + e * IMG + abase[i] + toff);
 #pragma unroll
                 for (int ea = 0; ea < NS; ++ea)
 #pragma unroll
@@ -246,8 +253,9 @@ __global__ __launch_bounds__(256, 2) void conv2_fwd_kernel(FwdArgs a) {
             const float bv = bias[n];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int W = (wave + 4 * i) * 8 + 2 * g + h;
-                if (W >= NWIN) continue;
+                const int slot = 2 * g + h, tl = wave + 4 * i;
+                if (slot == 7) continue;                   // (the eighth slot of a 7-window row)
+                const int W = (tl / P2) * CELLS2 + (tl % P2) * P2 + (int)((SLOT_CX >> (4 * slot)) & 7u);
                 float best = acc[i][j][4 * g]; int q = 0;
                 if (acc[i][j][4 * g + 1] > best) { best = acc[i][j][4 * g + 1]; q = 1; }
                 if (acc[i][j][4 * g + 2] > best) { best = acc[i][j][4 * g + 2]; q = 2; }
@@ -430,12 +438,13 @@ __global__ __launch_bounds__(256, 2) void conv2_dgrad_split_kernel(DgradArgs a) 
     };
 
     const int ntile = (NTILE - wave + 3) / 4;
-    int abase[MT];
+    int abase[MT], pl[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         int p = (wave + 4 * i) * 32 + r;
         if (p >= CELLS1) p = 0;
-        abase[i] = (p / P1) * G::XRS + (p % P1) * 64 + h * 16;
+        pl[i] = p + 4 * h;                       // (rotation of the pixel read for a tap: ((p + tap) >> 2) + h + 2 ks)
+        abase[i] = (p / P1) * G::XRS + (p % P1) * 64;
     }
     f32x16 acc[MT];
 #pragma unroll
@@ -473,7 +482,9 @@ __global__ __launch_bounds__(256, 2) void conv2_dgrad_split_kernel(DgradArgs a) 
                     bf16x8 v;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] = (qc[i] == q) ? tv[e][i] : (__bf16)0.f;
-                    *reinterpret_cast<bf16x8*>(gimg + e * IMG + (Y + (q >> 1)) * G::XRS + (X + (q & 1)) * 64 + cg * 16) = v;
+                    const int Yq = Y + (q >> 1), Xq = X + (q & 1);
+                    *reinterpret_cast<bf16x8*>(gimg + e * IMG + Yq * G::XRS + Xq * 64 +
+                                               ((cg + ((P1 * Yq + Xq) >> 2)) & 3) * 16) = v;
                 }
             }
         }
@@ -485,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void conv2_dgrad_split_kernel(DgradArgs a) 
             bf16x8 wnext[WROUNDS];
             if (t + 1 < G::T) wload(t + 1, pass, wnext);
             const unsigned char* wb = wbuf[t & 1] + r * WRS + h * 16;
-            const int toff = ky * G::XRS + kx * 64;
+            const int toff = ky * G::XRS + kx * 64, tapl = P1 * ky + kx;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 bfr[NS];
@@ -493,10 +504,12 @@ __global__ __launch_bounds__(256, 2) void conv2_dgrad_split_kernel(DgradArgs a) 
                 for (int e = 0; e < NS; ++e) bfr[e] = *reinterpret_cast<const bf16x8*>(wb + e * WSL + ks * 32);
                 bf16x8 af[MT][NS];
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                for (int i = 0; i < MT; ++i) {
+                    const int off = abase[i] + toff + ((((pl[i] + tapl) >> 2) + 2 * ks) & 3) * 16;
 #pragma unroll
                     for (int e = 0; e < NS; ++e)
-                        af[i][e] = *reinterpret_cast<const bf16x8*>(gimg + e * IMG + abase[i] + toff + ks * 32);
+                        af[i][e] = *reinterpret_cast<const bf16x8*>(gimg + e * IMG + off);
+                }
 #pragma unroll
                 for (int ea = 0; ea < NS; ++ea)
 #pragma unroll

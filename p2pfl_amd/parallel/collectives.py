@@ -47,6 +47,8 @@ class DeviceExchange:
         self._link_keys: Dict[tuple, bytes] = {}     # negotiated random keys, (lo, hi) -> 16 bytes
         self._idx_cache: Dict[tuple, torch.Tensor] = {}
         self._send_buf: Optional[torch.Tensor] = None
+        self._recv_buf: Optional[torch.Tensor] = None      # ciphertext of the rows received (encrypted exchange)
+        self._wire_buf: Optional[torch.Tensor] = None      # per-peer ciphertexts / receive slots of the encrypted all-reduce
         self._crypt_buf: Dict[int, torch.Tensor] = {}
         self.bytes_sent = 0                     # payload bytes this rank pushed to peers (metrics)
         self.bytes_encrypted = 0                # bytes that went through the link cipher (both directions)
@@ -164,12 +166,18 @@ class DeviceExchange:
         if self.encrypt:
             off = 0
             for r, c in enumerate(send_counts):
-                if c:
-                    send_cat[off:off + c] = self.crypt(send_cat[off:off + c], r, decrypt=False)
+                if c:       # in place: AES-ECB maps 16-byte blocks independently, so source == destination is fine
+                    self.crypt(send_cat[off:off + c], r, decrypt=False, out=send_cat[off:off + c])
                     off += c
         if self._backend() == "nccl":
-            # plaintext rows land straight in the staging buffer the reduce kernel reads; ciphertext in a scratch
-            recv_cat = staging[:n_recv] if not self.encrypt else torch.empty(n_recv, P, device=self.device)
+            # plaintext rows land straight in the staging buffer the reduce kernel reads; ciphertext in a scratch that
+            # is kept between rounds (a steady-state round allocates nothing)
+            if self.encrypt:
+                if self._recv_buf is None or self._recv_buf.shape[0] < max(n_recv, 1) or self._recv_buf.shape[1] != P:
+                    self._recv_buf = torch.empty(max(n_recv, 1), P, device=self.device)
+                recv_cat = self._recv_buf[:n_recv]
+            else:
+                recv_cat = staging[:n_recv]
             dist.all_to_all_single(recv_cat, send_cat, output_split_sizes=list(recv_counts),
                                    input_split_sizes=send_counts, group=self.pg)
         else:
@@ -212,8 +220,13 @@ class DeviceExchange:
             else:
                 dist.all_reduce(partial, group=self.pg)
             return partial
-        enc = [self.crypt(partial, r, False).clone() if r != self.rank else partial for r in range(self.world)]
-        outs = [torch.empty_like(partial) for _ in range(self.world)]
+        # per-peer ciphertexts and receive slots live in one buffer kept between rounds: [2, world, *partial.shape]
+        shape = (2, self.world) + tuple(partial.shape)
+        if self._wire_buf is None or tuple(self._wire_buf.shape) != shape or self._wire_buf.device != partial.device:
+            self._wire_buf = torch.empty(shape, dtype=partial.dtype, device=partial.device)
+        enc = [self.crypt(partial, r, False, out=self._wire_buf[0, r]) if r != self.rank else partial
+               for r in range(self.world)]
+        outs = [self._wire_buf[1, r] for r in range(self.world)]
         self.all_to_all(outs, enc)
         total = torch.zeros_like(partial)
         for r, o in enumerate(outs):

@@ -428,8 +428,11 @@ class HipEngine(ShardEngine):
         self._head = None
         last = len(self.spec.layers) - 1
         ll = self.spec.layers[last]
+        # (one workgroup per client: below ~32 clients the kernel leaves most of the chip idle and the four small
+        # kernels it replaces are faster - 10 clients: 86 us per step against 44; P2PFL_HEAD_MIN_K overrides)
         if (ll.kind == "linear" and last > 0 and not ll.relu and last not in self._fused
-                and not os.environ.get("P2PFL_NO_HEAD") and hip.linear_head_accepts(B, ll.in_features, ll.out_features)):
+                and not os.environ.get("P2PFL_NO_HEAD") and K >= int(os.environ.get("P2PFL_HEAD_MIN_K", "32"))
+                and hip.linear_head_accepts(B, ll.in_features, ll.out_features)):
             self._head = last
         if o.kind in ("adam", "sgd") and fuse_optimizer and not os.environ.get("P2PFL_NO_FUSE") \
                 and not os.environ.get("P2PFL_NO_FOLD"):

@@ -234,6 +234,7 @@ def test_client_groups_match_the_plain_pipeline(monkeypatch):
     from p2pfl_amd.runtime.engine import HipEngine
     spec = get_spec("mnist-cnn")
     K = 84
+    monkeypatch.setenv("P2PFL_HEAD_MIN_K", "1")      # the 28-client oracles take the one-kernel class head like the groups
     data = synthetic_shards(K, 80, 16, 40, spec.num_classes, seed=5, device="cuda")
     init = HipEngine(spec, K, "cuda", seed=7, use_graph=False)
     init.init_params(identical=False)

@@ -7,7 +7,7 @@ set -o pipefail
 out=${1:-gpurun_out/pmc}; shift
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-export P2PFL_INORDER=1
+export P2PFL_INORDER=${PMC_INORDER-1}      # PMC_INORDER= (empty): the shipped schedule (client groups: 50-client launches)
 run() {  # name, counters...
   name=$1; shift
   timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-graph $EXTRA > "$out/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$out/$name.log"; return 1; }

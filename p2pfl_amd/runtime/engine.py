@@ -494,6 +494,20 @@ class HipEngine(ShardEngine):
             self._act_pp = [self.act[self.nc - 1], torch.zeros_like(self.act[self.nc - 1])]
         # exact-split policy, update without fused data gradient (small shards): the stage-2 weight gradient runs on the
         # launch stream in front of the fused update (P2PFL_WGRAD_MAIN=0/1 overrides)
+        # Models whose step is a chain of short convolution kernels (FEMNIST-CNN: no HBM-bound update to hide under, so
+        # no two-stream pipeline) still have two INDEPENDENT chains in their backward pass: the weight gradients of the
+        # dense head and of the stage-2 convolution (+ their optimizer steps) need nothing from the data-gradient chain
+        # conv2 dgrad -> conv1 wgrad. They run on a second stream beside it (fork after the loss, join before the next
+        # forward). P2PFL_BWD_FORK=0 keeps the in-order backward.
+        convs = [i for i, l in enumerate(self.spec.layers) if l.kind != "linear"]
+        self._bwd_fork = (not self.overlap and self._head is None and o.kind in ("adam", "sgd")
+                          and any(l.kind == "conv2pool" for l in self.spec.layers)
+                          and len(self.spec.layers) == len(convs) + 1 and self.spec.layers[-1].kind == "linear"
+                          and len(self.spec.layers) - 1 not in self._fused
+                          and all(i in self._fold for i in convs)     # their steps ride in their gradient kernels
+                          and os.environ.get("P2PFL_BWD_FORK", "1") != "0")
+        if self._bwd_fork:
+            self._side = torch.cuda.Stream(device=dev)
         env = os.environ.get("P2PFL_WGRAD_MAIN")
         self._wgrad_on_main = (self.overlap and self.nc >= 2 and self.spec.layers[self.nc - 1].kind == "conv2pool"
                                and (self.precision == "fp32" if env is None else env != "0"))
@@ -514,6 +528,7 @@ class HipEngine(ShardEngine):
         if getattr(self, "_side", None) is not None:
             self._side = None
             self.overlap = False          # (a closed engine that is used again runs the single-stream schedule)
+            self._bwd_fork = False
         _LIVE_ENGINES.discard(self)
 
     EVAL_B = 256
@@ -664,6 +679,9 @@ class HipEngine(ShardEngine):
         hip, layers = self.hip, self.spec.layers
         o = self.spec.optim
         dy = self.dact[-1]
+        if self._bwd_fork:
+            self._backward_forked(data, sidx, step_index)
+            return
         for i in range(len(layers) - 1, -1, -1):
             l = layers[i]
             W, _ = self._w(self.params, l)
@@ -705,6 +723,52 @@ class HipEngine(ShardEngine):
             else:  # conv1pool (first layer: no data gradient)
                 hip.conv1_wgrad(dy, self.code[i], data, sidx, gW, gb, l.ksize, scratch=self.c1_scratch[i],
                                 opt=self._opt_epilogue(i, step_index))
+
+    def _backward_forked(self, data, sidx, step_index: int) -> None:
+        """Backward pass + optimizer step with the weight-gradient chain on a second stream (see ``_bwd_fork``):
+
+            launch stream :  head dgrad --ev--> conv2 dgrad -> conv1 wgrad (+ folded step) ............ join
+            side stream   :  head wgrad ......--ev--> head optimizer step -> conv2 wgrad (+ folded step) --^
+
+        The head's optimizer step waits for the head's data gradient (it reads the weights the step overwrites); the
+        stage-2 data gradient reads the PREPARED weight copy of the forward pass, so the stage-2 step may run beside it."""
+        hip, layers = self.hip, self.spec.layers
+        main, side = torch.cuda.current_stream(), self._side
+        last = len(layers) - 1
+        l = layers[last]
+        W, _ = self._w(self.params, l)
+        gW, gb = self._w(self.grads, l)
+        dy = self.dact[-1]
+        xin = self.act[last - 1].flatten(2) if self.act[last - 1].dim() > 3 else self.act[last - 1]
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            hip.linear_wgrad(dy, xin, gW, gb)
+        prev = layers[last - 1]
+        mask = self.act[last - 1] if (prev.kind == "linear" and prev.relu) else None
+        dx = self.dact[last - 1].flatten(2) if self.dact[last - 1].dim() > 3 else self.dact[last - 1]
+        hip.linear_dgrad(dy, W, mask, dx)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            self._optim_step(step_index)          # everything no gradient kernel updates itself: the head
+        dy = self.dact[last - 1]
+        for i in range(last - 1, -1, -1):
+            l = layers[i]
+            W, _ = self._w(self.params, l)
+            gW, gb = self._w(self.grads, l)
+            if l.kind == "conv2pool":
+                with torch.cuda.stream(side):
+                    hip.conv2_wgrad(dy, self.code[i], self.act[i - 1], gW, gb, l.ksize, scratch=self.w2_scratch[i],
+                                    opt=self._opt_epilogue(i, step_index))
+                hip.conv2_dgrad(dy, self.code[i], W, self.dact[i - 1], l.ksize, wprep=self.wprep[i])
+                dy = self.dact[i - 1]
+            elif l.kind == "conv1pool":
+                hip.conv1_wgrad(dy, self.code[i], data, sidx, gW, gb, l.ksize, scratch=self.c1_scratch[i],
+                                opt=self._opt_epilogue(i, step_index))
+            else:
+                raise RuntimeError("forked backward: dense layers below the head are not covered")
+        main.wait_stream(side)
 
     def _fused_update(self, l, dy, xin, step_index: int, sidx=None, dx=None) -> bool:
         """Weight gradient of a big linear layer + its optimizer update in one kernel. With ``dx`` the kernel is
@@ -825,7 +889,8 @@ class HipEngine(ShardEngine):
                 self._forward(self.train_x, sidx, self.train_y, nv, "Train", train=True)
                 t += 1
                 self._backward(self.train_x, sidx, t)
-                self._optim_step(t)
+                if not self._bwd_fork:             # (the forked backward runs the step on its side stream)
+                    self._optim_step(t)
             if self.val_x is not None:
                 self._eval_pass(self.val_x, self.val_y, "Validation")
 

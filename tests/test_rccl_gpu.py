@@ -77,3 +77,38 @@ def test_one_rank_federation_round_over_rccl(nccl_group):
         res.append(fed.engine.params.clone())
         fed.engine.close()
     assert torch.equal(res[0], res[1])
+
+
+def test_host_side_gloo_group_beside_the_rccl_group_and_steady_state_allocations(nccl_group):
+    """What a multi-rank job adds on the GPU box: (1) the host-side gloo group that the ranks use to agree on
+    evictions / STOP / gateways (runtime/federation.py ``ensure_host_group``, runtime/host.py ``_agree``) is created
+    BESIDE the RCCL group and reduces CPU tensors while RCCL owns the device; (2) the row exchange keeps its buffers:
+    after the first round an (encrypted) exchange allocates no device memory."""
+    import torch.distributed as dist
+    from p2pfl_amd.parallel.collectives import DeviceExchange
+    host = dist.new_group(backend="gloo")
+    assert dist.get_backend(host) == "gloo" and dist.get_backend(nccl_group) == "nccl"
+    flags = torch.tensor([1, 0, 1], dtype=torch.uint8)
+    dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=host)
+    dev = torch.ones(4, device="cuda")
+    dist.all_reduce(dev, group=nccl_group)                      # ... and RCCL still works next to it
+    torch.cuda.synchronize()
+    assert flags.tolist() == [1, 0, 1] and dev.tolist() == [1.0] * 4
+    P = 8192
+    params = torch.randn(8, P, device="cuda")
+    staging = torch.zeros(4, P, device="cuda")
+    part = torch.randn(1, P, device="cuda")
+    for encrypt in (False, True):
+        ex = DeviceExchange(0, 1, nccl_group, "cuda", encrypt=encrypt, scenario="t")
+        ex.exchange_rows(params, [[0, 3, 5, 6]], [4], staging)      # round 1: buffers, index tensors, round keys
+        if not encrypt:
+            ex.allreduce_partial(part)
+        torch.cuda.synchronize()
+        before = torch.cuda.memory_stats()["allocation.all.allocated"]
+        for _ in range(3):
+            ex.exchange_rows(params, [[0, 3, 5, 6]], [4], staging)
+            if not encrypt:
+                ex.allreduce_partial(part)
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_stats()["allocation.all.allocated"] == before, encrypt
+        assert torch.equal(staging, params[[0, 3, 5, 6]])

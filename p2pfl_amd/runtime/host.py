@@ -445,6 +445,9 @@ class FederationHost:
     def stop(self) -> None:
         self.stop_learning()
         self._terminate.set()
+        if self._service is not None and self._service is not threading.current_thread():
+            self._service.join(timeout=5)
+        self.bus.pump()          # what was published after the service thread's last turn still reaches gateways / ranks
         for gw in list(self.gateways.values()):
             gw.stop()
         if self._learning_thread is not None:
@@ -662,8 +665,9 @@ class FederationHost:
         self.round, self.totalrounds, self.epochs = 0, int(rounds), int(epochs)
         self.fed.epochs = int(epochs)
         self._stop.clear()
-        self._learning_thread = threading.Thread(target=self._learn, name="federation-learning", daemon=True)
-        self._learning_thread.start()
+        t = threading.Thread(target=self._learn, name="federation-learning", daemon=True)
+        t.start()
+        self._learning_thread = t          # published only once started: wait_started() / wait_finished() may join it
 
     def stop_learning(self) -> None:
         """``Node.set_stop_learning`` of a virtual node: the run ends after the round in flight - on every rank (the

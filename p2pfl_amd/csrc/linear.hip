@@ -188,6 +188,82 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(DgradArgs a) {
         sm, al, bl, epi, blockIdx.y * 32, blockIdx.x * 128, 0, a.Out);
 }
 
+// ---------------------------------------------------------------------------------------
+// Split reduction for shards with too few tiles to fill the chip (10 clients x 16 column tiles = 160 workgroups for
+// the MNIST-CNN l1 forward on 256 CUs: 84 us for 257 MB of weights, 3 TB/s). The reduction (In for the forward, Out
+// for the data gradient) is cut into S ranges of whole k-steps, one workgroup each; their raw partial tiles go to a
+// scratch buffer [K][S][B][N] and a finishing pass adds them up IN RANGE ORDER (bitwise reproducible) and applies the
+// epilogue of the unsplit kernel (bias + ReLU, or the ReLU mask of the producer layer).
+// ---------------------------------------------------------------------------------------
+struct EpiPartialStore {
+    float* part; int M, N;
+    __device__ __forceinline__ void operator()(const f32x16& acc, int m0, int n0) const {
+        const int lane = threadIdx.x & 63;
+        const int n = n0 + (lane & 31);
+        if (n >= N) return;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = m0 + mfma_row(e, lane);
+            if (m < M) part[(size_t)m * N + n] = acc[e];
+        }
+    }
+};
+
+// k range [k0, k1) of split z out of S over a reduction of `len` in steps of BK
+__device__ __forceinline__ void split_range(int len, int BK, int S, int z, int& k0, int& k1) {
+    const int steps = (len + BK - 1) / BK, per = (steps + S - 1) / S;
+    k0 = min(z * per, steps) * BK;
+    k1 = min(min((z + 1) * per, steps) * BK, len);
+}
+
+template <int BK, class T>
+__global__ __launch_bounds__(256) void linear_fwd_splitk_kernel(LinearArgs a, int S) {
+    __shared__ GemmSmem<32, 128, 2, BK, T> sm;
+    const int c = blockIdx.z, rt = blockIdx.y / S, z = blockIdx.y % S;
+    const float* x = a.x + c * a.x_cs;
+    const float* w = a.w + c * a.w_cs;
+    LoadRowMajorK al{x, a.B, a.In, a.In, (bool)(a.vec & 1), a.sidx ? a.sidx + c * a.s_cs : nullptr};
+    LoadRowMajorK bl{w, a.Out, a.In, a.In, (bool)(a.vec & 2)};
+    EpiPartialStore epi{a.part + ((size_t)c * S + z) * a.B * a.Out, a.B, a.Out};
+    int k0, k1;
+    split_range(a.In, BK, S, z, k0, k1);
+    gemm_block_tile<32, 128, 1, 4, LoadRowMajorK, LoadRowMajorK, EpiPartialStore, false, 2, BK, T>(
+        sm, al, bl, epi, rt * 32, blockIdx.x * 128, k0, k1);
+}
+
+template <int BK, class T>
+__global__ __launch_bounds__(256) void linear_dgrad_splitk_kernel(DgradArgs a, float* part, int S) {
+    __shared__ GemmSmem<32, 128, 2, BK, T> sm;
+    const int c = blockIdx.z, rt = blockIdx.y / S, z = blockIdx.y % S;
+    LoadRowMajorK al{a.dy + c * a.dy_cs, a.B, a.Out, a.Out, (bool)a.vec};
+    LoadColMajorK bl{a.w + c * a.w_cs, a.In, a.Out, a.In};
+    EpiPartialStore epi{part + ((size_t)c * S + z) * a.B * a.In, a.B, a.In};
+    int k0, k1;
+    split_range(a.Out, BK, S, z, k0, k1);
+    gemm_block_tile<32, 128, 1, 4, LoadRowMajorK, LoadColMajorK, EpiPartialStore, false, 2, BK, T>(
+        sm, al, bl, epi, rt * 32, blockIdx.x * 128, k0, k1);
+}
+
+// y[c][m][n] = epilogue(sum_z part[c][z][m][n]):  bias != null: + bias[n], then ReLU if `relu` (forward);
+// act != null: zero where act[c][m][n] <= 0 (data gradient). One thread per output element, z ascending.
+__global__ __launch_bounds__(256) void linear_splitk_finish_kernel(const float* part, int S, float* y, long y_cs,
+                                                                   const float* bias, long b_cs, const float* act,
+                                                                   long act_cs, int M, int N, int relu) {
+    const int c = blockIdx.y;
+    const long mn = (long)M * N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < mn; i += (long)gridDim.x * 256) {
+        const float* p = part + (size_t)c * S * mn + i;
+        float v = 0.f;
+        for (int z = 0; z < S; ++z) v += p[(size_t)z * mn];
+        if (bias != nullptr) {
+            v += bias[c * b_cs + i % N];
+            if (relu) v = fmaxf(v, 0.f);
+        }
+        if (act != nullptr && !(act[c * act_cs + i] > 0.f)) v = 0.f;
+        y[c * y_cs + i] = v;
+    }
+}
+
 struct WgradArgs {
     const float* dy; long dy_cs;  // [K][B][Out]
     const float* x;  long x_cs;   // [K][B][In]
@@ -786,11 +862,35 @@ static int skinny_splits(int K, int B, int In) {
     return ks;
 }
 
+// Ranges a tiled product with `tiles` workgroups splits its reduction of `len` into (see linear_fwd_splitk_kernel):
+// as many as keep the grid within three workgroups per CU, each range >= 16 k-steps of 32; 1 = do not split.
+// fp32 policies only (the bf16 kernels of a sparse grid take 128-deep steps instead). P2PFL_SPLITK=0 disables.
+static int tile_splits(long tiles, int len, int prec) {
+    static const bool off = [] { const char* e = getenv("P2PFL_SPLITK"); return e && atoi(e) == 0; }();
+    if (off || prec == PREC_BF16 || tiles <= 0 || tiles > num_cus() || len < 1024) return 1;
+    long s = 3L * num_cus() / tiles;
+    const long cap = len / (16 * 32);
+    if (s > cap) s = cap;
+    if (s > 8) s = 8;
+    return s < 2 ? 1 : (int)s;
+}
+
 // floats of scratch p2pfl_linear_fwd wants for this problem (0: none)
 P2PFL_API long p2pfl_linear_fwd_scratch(int K, int B, int In, int Out) {
-    if (K <= 0 || B <= 0 || !(Out <= 64 && In >= 512 && (long)K * cdiv(B, 32) <= 2L * num_cus())) return 0;
+    if (K <= 0 || B <= 0) return 0;
+    if (!(Out <= 64 && In >= 512 && (long)K * cdiv(B, 32) <= 2L * num_cus())) {
+        const int S = tile_splits((long)cdiv(Out, 128) * cdiv(B, 32) * K, In, PREC_F32);
+        return S > 1 ? (long)K * S * B * Out : 0;
+    }
     const int ks = skinny_splits(K, B, In);
     return ks > 1 ? (long)K * cdiv(B, 32) * ks * (Out <= 32 ? 1 : 2) * 1024 : 0;
+}
+
+// floats of scratch p2pfl_linear_dgrad wants for this problem (0: none)
+P2PFL_API long p2pfl_linear_dgrad_scratch(int K, int B, int In, int Out) {
+    if (K <= 0 || B <= 0) return 0;
+    const int S = tile_splits((long)cdiv(In, 128) * cdiv(B, 32) * K, Out, PREC_F32);
+    return S > 1 ? (long)K * S * B * In : 0;
 }
 
 P2PFL_API int p2pfl_linear_fwd(const float* x, long x_cs, const float* w, long w_cs, const float* b,
@@ -820,6 +920,17 @@ P2PFL_API int p2pfl_linear_fwd(const float* x, long x_cs, const float* w, long w
         P2PFL_RETURN_LAST_ERROR();
     }
     dim3 grid(cdiv(Out, 128), cdiv(B, 32), K);
+    {   // few tiles, long reduction: split it (fp32 policies; needs the caller's scratch)
+        const int S = tile_splits((long)grid.x * grid.y * grid.z, In, prec);
+        if (S > 1 && scratch != nullptr && scratch_floats >= (long)K * S * B * Out && K <= 65535) {
+            const dim3 sgrid(grid.x, grid.y * S, K);
+            hipLaunchKernelGGL((linear_fwd_splitk_kernel<32, float>), sgrid, dim3(256), 0, stream, a, S);
+            const int fx = (int)(((long)B * Out + 255) / 256);
+            hipLaunchKernelGGL(linear_splitk_finish_kernel, dim3(fx < 64 ? fx : 64, K), dim3(256), 0, stream, scratch, S, y,
+                               y_cs, b, b_cs, (const float*)nullptr, 0L, B, Out, relu);
+            P2PFL_RETURN_LAST_ERROR();
+        }
+    }
     // long reductions (MNIST-CNN l1: In = 3136) take 64-deep k-steps: half the barriers / twice the bytes in
     // flight per step (100 clients on MI355X: 546 -> 516 us; 128-deep steps cost occupancy: 514-589 us)
     // few clients: at most one block per CU, so the bytes in flight per block bound the bandwidth -> 128-deep
@@ -840,12 +951,23 @@ P2PFL_API int p2pfl_linear_fwd(const float* x, long x_cs, const float* w, long w
 
 P2PFL_API int p2pfl_linear_dgrad(const float* dy, long dy_cs, const float* w, long w_cs,
                                  const float* act, long act_cs, float* dx, long dx_cs, int K, int B,
-                                 int In, int Out, int prec, hipStream_t stream) {
+                                 int In, int Out, float* scratch, long scratch_floats, int prec, hipStream_t stream) {
     if (K <= 0 || B <= 0 || In <= 0 || Out <= 0) return -1;
     // dy rows of e.g. 10 classes are not 16-B aligned: element loads then
     const int vec = !((Out & 3) || (dy_cs & 3) || ((uintptr_t)dy & 15));
     DgradArgs a{dy, dy_cs, w, w_cs, act, act_cs, dx, dx_cs, B, In, Out, vec};
     dim3 grid(cdiv(In, 128), cdiv(B, 32), K);
+    {   // few tiles, long reduction: split it (see linear_dgrad_splitk_kernel)
+        const int S = tile_splits((long)grid.x * grid.y * grid.z, Out, prec);
+        if (S > 1 && scratch != nullptr && scratch_floats >= (long)K * S * B * In && K <= 65535) {
+            const dim3 sgrid(grid.x, grid.y * S, K);
+            hipLaunchKernelGGL((linear_dgrad_splitk_kernel<32, float>), sgrid, dim3(256), 0, stream, a, scratch, S);
+            const int fx = (int)(((long)B * In + 255) / 256);
+            hipLaunchKernelGGL(linear_splitk_finish_kernel, dim3(fx < 64 ? fx : 64, K), dim3(256), 0, stream, scratch, S, dx,
+                               dx_cs, (const float*)nullptr, 0L, act, act_cs, B, In, 0);
+            P2PFL_RETURN_LAST_ERROR();
+        }
+    }
     const bool sparse_grid = (long)grid.x * grid.y * grid.z <= num_cus() && getenv("P2PFL_NO_BK128") == nullptr;
     if (prec != PREC_BF16) {
         if (Out >= 1024 && sparse_grid) hipLaunchKernelGGL((linear_dgrad_kernel<64, 2, float>), grid, dim3(256), 0, stream, a);

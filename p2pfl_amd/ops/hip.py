@@ -117,7 +117,8 @@ def _prec(prec) -> int:
 class _Sig:
     p2pfl_linear_fwd = [P, L, P, L, P, L, P, L, I, I, I, I, I, P, L, P, L, I, P]
     p2pfl_linear_fwd_scratch = [I, I, I, I]
-    p2pfl_linear_dgrad = [P, L, P, L, P, L, P, L, I, I, I, I, I, P]
+    p2pfl_linear_dgrad = [P, L, P, L, P, L, P, L, I, I, I, I, P, L, I, P]
+    p2pfl_linear_dgrad_scratch = [I, I, I, I]
     p2pfl_linear_wgrad = [P, L, P, L, P, L, P, L, I, I, I, I, P, L, I, P]
     p2pfl_linear_wgrad_adam = [P, L, P, L, P, P, P, L, P, P, P, L, I, I, I, I, F, F, F, F, F, I, P, I, P, L, I, P]
     p2pfl_linear_wgrad_adam_dgrad = [P, L, P, L, P, P, P, L, P, P, P, L, P, L, I, I, I, I, F, F, F, F, F, I, P, I, P, L, I, P]
@@ -246,13 +247,34 @@ def linear_fwd(x, w, b, y, relu: bool, sidx=None, scratch: Optional[torch.Tensor
                               _prec(prec), stream), "linear_fwd")
 
 
-def linear_dgrad(dy, w, act, dx, prec=None) -> None:
-    """dx[k] = (dy[k] @ w[k]) * (act[k] > 0)   (act None: no mask)."""
+def linear_dgrad_scratch(K: int, B: int, In: int, Out: int, device) -> Optional[torch.Tensor]:
+    """Scratch buffer :func:`linear_dgrad` wants for this problem (None: none) - shards with too few tiles to fill the
+    chip split the reduction over several workgroups whose partial tiles go through it."""
+    need = int(load().p2pfl_linear_dgrad_scratch(K, B, In, Out))
+    return torch.empty(need, dtype=torch.float32, device=device) if need else None
+
+
+def linear_dgrad(dy, w, act, dx, scratch: Optional[torch.Tensor] = None, prec=None) -> None:
+    """dx[k] = (dy[k] @ w[k]) * (act[k] > 0)   (act None: no mask). ``scratch``: buffer from
+    :func:`linear_dgrad_scratch` owned by the caller; without it one per (device, stream, thread) is kept here."""
     K, B, Out = dy.shape
     In = w.shape[2]
     assert w.shape == (K, Out, In) and dx.shape == (K, B, In)
     (dp, ds), (wp, ws), (ap, as_), (xp, xs) = _pc(dy), _pc(w), _pc(act), _pc(dx)
-    _chk(load().p2pfl_linear_dgrad(dp, ds, wp, ws, ap, as_, xp, xs, K, B, In, Out, _prec(prec), _stream()),
+    lib = load()
+    stream = _stream()
+    need = int(lib.p2pfl_linear_dgrad_scratch(K, B, In, Out))
+    cp = 0
+    if need:
+        if scratch is not None and scratch.numel() >= need:
+            buf = _t(scratch)
+        else:
+            key = (dx.device, int(stream or 0), threading.get_ident(), "dgrad")
+            buf = _fwd_scratch.get(key)
+            if buf is None or buf.numel() < need:
+                buf = _fwd_scratch[key] = torch.empty(need, dtype=torch.float32, device=dx.device)
+        cp = buf.data_ptr()
+    _chk(lib.p2pfl_linear_dgrad(dp, ds, wp, ws, ap, as_, xp, xs, K, B, In, Out, cp, need, _prec(prec), stream),
          "linear_dgrad")
 
 

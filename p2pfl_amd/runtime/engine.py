@@ -565,6 +565,13 @@ class HipEngine(ShardEngine):
             self._fwd_scratch[key] = self.hip.linear_fwd_scratch(self.K, *key, self.device)
         self.hip.linear_fwd(x, W, b, y, relu, sidx=sidx, scratch=self._fwd_scratch[key])
 
+    def _linear_dgrad(self, dy, W, mask, dx) -> None:
+        """hip.linear_dgrad with an engine-owned scratch buffer per problem shape (made at the first, eager, call)."""
+        key = ("dgrad", dy.shape[1], W.shape[2], W.shape[1])
+        if key not in self._fwd_scratch:
+            self._fwd_scratch[key] = self.hip.linear_dgrad_scratch(self.K, *key[1:], self.device)
+        self.hip.linear_dgrad(dy, W, mask, dx, scratch=self._fwd_scratch[key])
+
     # ------------------------------------------------------------------ helpers
     def _w(self, slab, l):
         return self.layout.view2d(slab, l.weight), self.layout.view(slab, l.bias)
@@ -705,7 +712,7 @@ class HipEngine(ShardEngine):
                     if i in self._fused and mask is None and self._fuse_dgrad:
                         took = self._fused_update(l, dy, xin, step_index, sidx=gather, dx=dx)
                     if not took:
-                        hip.linear_dgrad(dy, W, mask, dx)
+                        self._linear_dgrad(dy, W, mask, dx)
                     dy_next = self.dact[i - 1]
                 if took:
                     pass
@@ -746,7 +753,7 @@ class HipEngine(ShardEngine):
         prev = layers[last - 1]
         mask = self.act[last - 1] if (prev.kind == "linear" and prev.relu) else None
         dx = self.dact[last - 1].flatten(2) if self.dact[last - 1].dim() > 3 else self.dact[last - 1]
-        hip.linear_dgrad(dy, W, mask, dx)
+        self._linear_dgrad(dy, W, mask, dx)
         ev = torch.cuda.Event()
         ev.record(main)
         with torch.cuda.stream(side):
@@ -974,7 +981,7 @@ class HipEngine(ShardEngine):
                 # hide under the update anyway, see docs/kernels.rst), so the side stream is released after it
                 took = self._fused_update(l, self.dact[i], xin, step_index, dx=self.dact[i - 1].flatten(2))
             if not took:
-                hip.linear_dgrad(self.dact[i], W, mask, self.dact[i - 1].flatten(2))
+                self._linear_dgrad(self.dact[i], W, mask, self.dact[i - 1].flatten(2))
             if i == nc:
                 side.wait_stream(main)
                 self._wgrad_ev = None

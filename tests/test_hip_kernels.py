@@ -611,6 +611,40 @@ def test_aes128_ecb_known_answer_and_roundtrip():
     assert bytes(e2[:4096].cpu().tolist()) == ecb_host(key, bytes(big[:4096].cpu().tolist()), decrypt=False)
 
 
+@pytest.mark.parametrize("K,B", [(1, 32), (10, 32), (3, 17)])
+def test_linear_split_reduction_for_small_shards(K, B):
+    """Few clients x a long reduction (MNIST-CNN l1 for a 10-client shard: 160 forward / 250 data-gradient tiles on 256
+    CUs): the reduction is split over several workgroups and summed in range order by a finishing pass that applies
+    bias + ReLU / the ReLU mask. Same numbers as the unsplit kernels' oracle, bitwise reproducible."""
+    from p2pfl_amd.ops import hip
+    lib = hip.load()
+    In, Out = 3136, 2048
+    assert lib.p2pfl_linear_fwd_scratch(K, B, In, Out) > 0 and lib.p2pfl_linear_dgrad_scratch(K, B, In, Out) > 0
+    assert lib.p2pfl_linear_fwd_scratch(100, B, In, Out) == 0      # (100 clients fill the chip: no split)
+    torch.manual_seed(2)
+    x = torch.randn(K, B, In, device="cuda")
+    w = slab_view(K, (Out, In)) * 0.03
+    b = slab_view(K, (Out,))
+    y = torch.full((K, B, Out), float("nan"), device="cuda")
+    hip.linear_fwd(x, w, b, y, True, prec="fp32")
+    ref = (torch.einsum("kbi,koi->kbo", x.double(), w.double()) + b.double()[:, None]).relu()
+    assert rel_err(y.double(), ref) < 2e-6
+    y2 = torch.empty_like(y)
+    hip.linear_fwd(x, w, b, y2, True, prec="fp32")
+    assert torch.equal(y, y2)
+    dy = torch.randn(K, B, Out, device="cuda")
+    act = torch.randn(K, B, In, device="cuda")
+    dx = torch.full((K, B, In), float("nan"), device="cuda")
+    hip.linear_dgrad(dy, w, act, dx, prec="fp32")
+    refd = torch.einsum("kbo,koi->kbi", dy.double(), w.double()) * (act > 0)
+    assert rel_err(dx.double(), refd) < 2e-6 and ((dx == 0) | (act > 0)).all()
+    dx2 = torch.empty_like(dx)
+    hip.linear_dgrad(dy, w, act, dx2, prec="fp32")
+    assert torch.equal(dx, dx2)
+    hip.linear_dgrad(dy, w, None, dx2, prec="fp32")
+    assert rel_err(dx2.double(), torch.einsum("kbo,koi->kbi", dy.double(), w.double())) < 2e-6
+
+
 @pytest.mark.parametrize("deep", [True, False])
 @pytest.mark.parametrize("In,Out", [(1024, 96), (1100, 70)])
 def test_linear_long_reduction_variants(In, Out, deep, monkeypatch, prec):

@@ -64,5 +64,7 @@ class MNISTDataModule(FederatedDataModule):
             cls.mnist_train, cls.mnist_val, cls.synthetic = (to_x(tx), to_y(ty)), (to_x(ex), to_y(ey)), False
         else:
             logging.warning("[MNIST] IDX files not found under %s: using the synthetic MNIST-shaped set", root)
-            tx, ty, ex, ey = synthetic_classification(60000, 10000, 784, 10, seed=1234)
+            # (P2PFL_SYNTHETIC_MNIST_ROWS: a smaller stand-in, e.g. for launcher tests that train on the CPU)
+            n_tr = int(os.environ.get("P2PFL_SYNTHETIC_MNIST_ROWS", "60000"))
+            tx, ty, ex, ey = synthetic_classification(n_tr, max(n_tr // 6, 100), 784, 10, seed=1234)
             cls.mnist_train, cls.mnist_val, cls.synthetic = (tx, ty), (ex, ey), True

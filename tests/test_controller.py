@@ -69,7 +69,8 @@ def test_docker_compose_generation(tmp_path):
 
 
 @pytest.mark.slow
-def test_batched_launcher_runs_scenario(tmp_path):
+def test_batched_launcher_runs_scenario(tmp_path, monkeypatch):
+    monkeypatch.setenv("P2PFL_SYNTHETIC_MNIST_ROWS", "12000")     # (the launcher process trains on the CPU here)
     a = args_for(tmp_path, topology="ring", engine="batched")
     Controller.generate_participants(os.path.join(a.config, "scen"), 4, "DFL", "MNIST", "MLP", rounds=2, epochs=1,
                                      accelerator="cpu", controller="")
@@ -118,6 +119,7 @@ def test_batched_launcher_faults_checkpoints_and_resume(tmp_path):
 
 @pytest.mark.slow
 def test_config1_two_processes_tcp_mnist_mlp(tmp_path, monkeypatch):
+    monkeypatch.setenv("P2PFL_SYNTHETIC_MNIST_ROWS", "12000")
     monkeypatch.setenv("P2PFL_START_DELAY", "1")
     monkeypatch.setenv("P2PFL_LAUNCH_GAP", "0.5")
     a = args_for(tmp_path, engine="process")

@@ -209,11 +209,17 @@ class LightningLearner(NodeLearner):
             total += float(loss.detach()) * len(xb)
             n += len(xb)
             steps += 1
+            idx = None
             if cm is not None and pred is not None:
                 idx = (yb.long().cpu() * C + pred.long().cpu()).clamp(0, C * C - 1)
                 cm.view(-1).index_add_(0, idx, torch.ones_like(idx))
             if train and steps % 20 == 0:
-                self._log({f"{phase}/Loss": float(loss.detach())}, step=self._local_step + steps)
+                # the per-step series: loss + macro metrics of THIS batch (mnist/models/mlp.py:33-106, every 20 steps)
+                row = {f"{phase}/Loss": float(loss.detach())}
+                if idx is not None:
+                    bcm = torch.zeros(C * C, dtype=torch.int64).index_add_(0, idx, torch.ones_like(idx)).view(C, C)
+                    row.update({f"{phase}/{k}": v for k, v in metrics_from_confusion(bcm).items() if k != "MicroAccuracy"})
+                self._log(row, step=self._local_step + steps)
         return total / max(n, 1), cm, steps
 
     # ------------------------------------------------------------------ fit / evaluate

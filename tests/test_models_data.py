@@ -298,6 +298,17 @@ def test_loggers_fl_stepping_and_files(tmp_path):
     # FL-aware stepping: steps of round 2 continue after those of round 1 (global_step + local_step)
     steps = [int(r.split(",")[1]) for r in rows[1:] if r.split(",")[2] == "TrainEpoch/Loss"]
     assert len(steps) == 2 and steps[1] == 2 * steps[0] and lg.global_step == steps[1]
+    # the per-step series of the reference's models (torchmetrics of the step's batch every 20 steps,
+    # mnist/models/mlp.py:33-106): loss AND macro metrics, at step 20 of a 34-step epoch
+    lg2 = CSVLogger(str(tmp_path), name="metrics", version="participant_2")
+    l2 = _learner(n=50, logger=lg2)
+    l2.set_epochs(1)
+    l2.fit()
+    lg2.finalize("success")
+    rows2 = [r.split(",") for r in (tmp_path / "metrics" / "participant_2" / "metrics.csv").read_text().strip().splitlines()[1:]]
+    at20 = {r[2]: float(r[3]) for r in rows2 if int(r[1]) == 20}
+    assert {"Train/Loss", "Train/Accuracy", "Train/Precision", "Train/Recall", "Train/F1Score"} <= set(at20)
+    assert all(0.0 <= at20[k] <= 1.0 for k in at20 if k != "Train/Loss")
     # TensorBoard event file: TFRecord framing with masked crc32c, readable scalar events
     tb = FedstellarLogger(str(tmp_path), name="tb", version="participant_1")
     tb.log_metrics({"Test/Loss": 1.5}, step=3)

@@ -69,7 +69,7 @@ def _host_worker(rank, world, port, gw_port, out, federation):
         assert host.wait_started(90)
         assert wait_for(lambda: host.round is None, 180)
         done = len(host.reports)          # (the last frames of the other rank are still on their way through the pumps)
-        wait_for(lambda: host.bus.counts["MODELS_READY"] >= N * done, 5)
+        wait_for(lambda: sum(h == b"MODELS_READY" for _, h in list(seen)) >= N * done, 15)   # delivered, not just queued
         out[rank] = dict(params=fed.engine.params.clone(), reports=len(host.reports), names=list(host.names),
                          network=host.network_nodes(), counts=dict(host.bus.counts),
                          beats=sorted({s for s, h in seen if h == b"BEAT"}),

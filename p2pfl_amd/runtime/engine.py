@@ -109,6 +109,91 @@ class ShardEngine:
         self._perm_calls = 0
         self.train_x = self.train_y = self.val_x = self.val_y = self.test_x = self.test_y = None
         self.opt_steps = 0
+        self._init_step_log(False)
+
+    # ------------------------------------------------------------------ per-step Train/* series
+    LOG_EVERY = 20
+
+    def _init_step_log(self, log_steps: bool) -> None:
+        """log_steps: keep the running (loss sum, sample count) of every optimizer step of a ``fit`` in a device table
+        and, every LOG_EVERY steps, the confusion counters of that step and of the step before it - what the
+        reference's models log per step (Train/Loss + macro metrics of the batch, mnist/models/mlp.py:33-106;
+        log_every_n_steps=20, lightninglearner.py:188). Read back with step_losses / step_confusions / step_metrics."""
+        self.log_steps = bool(log_steps)
+        self._step_log = None
+        self._step_cm = None
+        self._cm_slot: Dict[int, int] = {}
+        self._step_pos = 0
+
+    def _alloc_step_tables(self, total: int) -> bool:
+        """Tables for a fit of ``total`` optimizer steps; True when they were (re)allocated."""
+        if not self.log_steps or (self._step_log is not None and self._step_log.shape[0] == total):
+            return False
+        self._step_log = torch.zeros(total, 2, self.K, device=self.device)
+        logged = [p for p in range(total) if (p + 1) % self.LOG_EVERY == 0]
+        self._cm_slot = {p: i for i, p in enumerate(sorted({q for p in logged for q in (p - 1, p)}))}
+        C = self.stats["Train"].confusion.shape[-1]
+        self._step_cm = torch.zeros(max(len(self._cm_slot), 1), self.K, C, C, dtype=torch.int32, device=self.device)
+        return True
+
+    def _record_client_step(self, pos: int, k: int) -> None:
+        """Per-client engines (one replica at a time): snapshot client k's running Train counters after step ``pos``."""
+        if self._step_log is None or pos >= self._step_log.shape[0]:
+            return
+        st = self.stats["Train"]
+        self._step_log[pos, 0, k] = st.loss_sum[k]
+        self._step_log[pos, 1, k] = st.count[k]
+        slot = self._cm_slot.get(pos)
+        if slot is not None:
+            self._step_cm[slot, k].copy_(st.confusion[k])
+
+    def step_confusions(self) -> Dict[int, torch.Tensor]:
+        """{step (1-based, every LOG_EVERY-th): [K, C, C] confusion matrix of THAT step's batch} of the last ``fit``
+        (needs ``log_steps``): the difference of the counters snapshotted inside the graph after this step and after
+        the one before it."""
+        if self._step_cm is None:
+            return {}
+        cms = self._step_cm.cpu().to(torch.int64)
+        out = {}
+        for pos, slot in sorted(self._cm_slot.items()):
+            if (pos + 1) % self.LOG_EVERY:
+                continue
+            cur = cms[slot]
+            d = cur - (cms[self._cm_slot[pos - 1]] if pos - 1 in self._cm_slot else 0)
+            reset = d.flatten(1).min(dim=1).values < 0        # the per-epoch statistics were reset between the two steps
+            d[reset] = cur[reset]
+            out[pos + 1] = d
+        return out
+
+    def step_metrics(self) -> Dict[int, List[Dict[str, float]]]:
+        """{step: per-client macro Accuracy / Precision / Recall / F1Score of that step's batch} - the per-step
+        ``Train/*`` series of the reference's models (mnist/models/mlp.py:33-106), derived on the host."""
+        from ..learning.metrics import metrics_from_confusion
+        out = {}
+        for step, cm in self.step_confusions().items():
+            rows = []
+            for k in range(cm.shape[0]):
+                m = metrics_from_confusion(cm[k])
+                m.pop("MicroAccuracy", None)
+                rows.append(m)
+            out[step] = rows
+        return out
+
+    def step_losses(self) -> Optional[torch.Tensor]:
+        """[steps, K] mean training loss of every optimizer step of the last ``fit`` (needs ``log_steps``)."""
+        if self._step_log is None:
+            return None
+        log = self._step_log.cpu()
+        prev = torch.zeros_like(log[0])
+        out = []
+        for t in range(log.shape[0]):
+            cur = log[t]
+            if (cur[1] < prev[1]).any():          # the per-epoch statistics were reset before this step
+                prev = torch.zeros_like(prev)
+            d = cur - prev
+            out.append(d[0] / d[1].clamp(min=1))
+            prev = cur
+        return torch.stack(out)
 
     # ------------------------------------------------------------------ parameters
     def init_params(self, seed: Optional[int] = None, identical: bool = True) -> None:
@@ -226,8 +311,9 @@ class ShardEngine:
 class EagerEngine(ShardEngine):
     """One ``nn.Module`` per client whose parameters alias the slab rows."""
 
-    def __init__(self, *a, **kw):
+    def __init__(self, *a, log_steps: bool = False, **kw):
         super().__init__(*a, **kw)
+        self._init_step_log(log_steps)
         self.modules: List[torch.nn.Module] = []
         for k in range(self.K):
             m = module_for_spec(self.spec).to(self.device)
@@ -240,7 +326,7 @@ class EagerEngine(ShardEngine):
         self.optims = [m.configure_optimizers() for m in self.modules]
         self.opt_steps = 0
 
-    def _run_phase(self, k, x, y, phase, train, optim=None, order=None):
+    def _run_phase(self, k, x, y, phase, train, optim=None, order=None, step0: int = 0):
         m = self.modules[k]
         st = self.stats[phase]
         n = x.shape[0]
@@ -263,12 +349,15 @@ class EagerEngine(ShardEngine):
             st.correct[k] += (pred == yb).sum().to(torch.int32)
             st.count[k] += len(idx)
             st.confusion[k].view(-1).index_add_(0, (yb * C + pred), torch.ones_like(pred, dtype=torch.int32))
+            if train:
+                self._record_client_step(step0 + s // self.B, k)
 
     def fit(self, epochs, active=None):
         if self.optims is None or not self.persist_optimizer:
             self.reset_optimizer()
         perms = self._epoch_perms(epochs).to(self.device).long()
         n = self.train_x.shape[1]
+        self._alloc_step_tables(epochs * self.steps_per_epoch())
         hist = []
         for e in range(epochs):
             self.stats["Train"].zero_(); self.stats["Validation"].zero_()
@@ -276,7 +365,8 @@ class EagerEngine(ShardEngine):
                 if active is not None and not bool(active[k]):
                     continue
                 self.modules[k].train()
-                self._run_phase(k, self.train_x[k], self.train_y[k], "Train", True, self.optims[k], perms[e, k, :n])
+                self._run_phase(k, self.train_x[k], self.train_y[k], "Train", True, self.optims[k], perms[e, k, :n],
+                                step0=e * self.steps_per_epoch())
                 if self.val_x is not None:
                     self.modules[k].eval()
                     self._run_phase(k, self.val_x[k], self.val_y[k], "Validation", False)
@@ -350,10 +440,7 @@ class HipEngine(ShardEngine):
         # difference is the confusion matrix of ONE batch, from which the host derives the per-step
         # Train/{Accuracy,Precision,Recall,F1Score} series of the reference's models (mnist/models/mlp.py:33-106:
         # torchmetrics on the step's batch, logged every 20 steps)
-        self.log_steps = bool(log_steps)
-        self._step_log = None
-        self._step_cm = None
-        self._cm_slot: Dict[int, int] = {}
+        self._init_step_log(log_steps)
         if self.device.type != "cuda":
             raise RuntimeError("HipEngine needs a GPU device")
         from ..ops import hip
@@ -622,8 +709,6 @@ class HipEngine(ShardEngine):
         if train:
             self._record_step()
 
-    LOG_EVERY = 20
-
     def _record_step(self) -> None:
         if self._step_log is not None and self._step_pos < self._step_log.shape[0]:
             st = self.stats["Train"]
@@ -633,54 +718,6 @@ class HipEngine(ShardEngine):
             if slot is not None and self._step_cm is not None:
                 self._step_cm[slot].copy_(st.confusion)
             self._step_pos += 1
-
-    def step_confusions(self) -> Dict[int, torch.Tensor]:
-        """{step (1-based, every LOG_EVERY-th): [K, C, C] confusion matrix of THAT step's batch} of the last ``fit``
-        (needs ``log_steps``): the difference of the counters snapshotted inside the graph after this step and after
-        the one before it."""
-        if self._step_cm is None:
-            return {}
-        cms = self._step_cm.cpu().to(torch.int64)
-        out = {}
-        for pos, slot in sorted(self._cm_slot.items()):
-            if (pos + 1) % self.LOG_EVERY:
-                continue
-            cur = cms[slot]
-            d = cur - (cms[self._cm_slot[pos - 1]] if pos - 1 in self._cm_slot else 0)
-            reset = d.flatten(1).min(dim=1).values < 0        # the per-epoch statistics were reset between the two steps
-            d[reset] = cur[reset]
-            out[pos + 1] = d
-        return out
-
-    def step_metrics(self) -> Dict[int, List[Dict[str, float]]]:
-        """{step: per-client macro Accuracy / Precision / Recall / F1Score of that step's batch} - the per-step
-        ``Train/*`` series of the reference's models (mnist/models/mlp.py:33-106), derived on the host."""
-        from ..learning.metrics import metrics_from_confusion
-        out = {}
-        for step, cm in self.step_confusions().items():
-            rows = []
-            for k in range(cm.shape[0]):
-                m = metrics_from_confusion(cm[k])
-                m.pop("MicroAccuracy", None)
-                rows.append(m)
-            out[step] = rows
-        return out
-
-    def step_losses(self) -> Optional[torch.Tensor]:
-        """[steps, K] mean training loss of every optimizer step of the last ``fit`` (needs ``log_steps``)."""
-        if self._step_log is None:
-            return None
-        log = self._step_log.cpu()
-        prev = torch.zeros_like(log[0])
-        out = []
-        for t in range(log.shape[0]):
-            cur = log[t]
-            if (cur[1] < prev[1]).any():          # the per-epoch statistics were reset before this step
-                prev = torch.zeros_like(prev)
-            d = cur - prev
-            out.append(d[0] / d[1].clamp(min=1))
-            prev = cur
-        return torch.stack(out)
 
     def _backward(self, data, sidx, step_index: int = 1) -> None:
         hip, layers = self.hip, self.spec.layers
@@ -1196,12 +1233,7 @@ class HipEngine(ShardEngine):
                 self._bc_buf = torch.zeros(bc.shape, device=self.device)
                 self._graphs.clear()
             self._bc_buf.copy_(bc, non_blocking=True)
-        if self.log_steps and (self._step_log is None or self._step_log.shape[0] != total):
-            self._step_log = torch.zeros(total, 2, self.K, device=self.device)
-            logged = [p for p in range(total) if (p + 1) % self.LOG_EVERY == 0]
-            self._cm_slot = {p: i for i, p in enumerate(sorted({q for p in logged for q in (p - 1, p)}))}
-            C = self.stats["Train"].confusion.shape[-1]
-            self._step_cm = torch.zeros(max(len(self._cm_slot), 1), self.K, C, C, dtype=torch.int32, device=self.device)
+        if self._alloc_step_tables(total):
             self._graphs.clear()
         saved = None
         if active is not None and not bool(torch.as_tensor(active).all()):

@@ -93,9 +93,8 @@ class BatchedFederation:
                                                client_offset=self.local.start,
                                                **({"use_graph": use_graph, "overlap": overlap, "precision": precision}
                                                   if engine != "eager" else {}),
-                                               # per-step Train/* series (HIP engine: snapshots inside the graph)
-                                               **({"log_steps": True} if log_steps and engine != "eager"
-                                                  and isinstance(spec, ModelSpec) and self.device.type == "cuda" else {}))
+                                               # per-step Train/* series (snapshots inside the captured graphs)
+                                               **({"log_steps": True} if log_steps else {}))
         # membership of ALL nodes of the scenario (every rank applies the same deterministic schedule)
         self.membership = VirtualMembership(self.N, heartbeat_period, node_timeout, instant=instant_detection)
         self.alive = np.ones(self.N, dtype=bool)                # the node's process is up (it evaluates / trains)

@@ -250,13 +250,15 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
         # engine takes inside its captured graph
         per_loss = fed.engine.step_losses() if hasattr(fed.engine, "step_losses") else None
         if per_loss is not None:
-            per_cm = fed.engine.step_metrics()
+            per_cm = fed.engine.step_metrics()          # {} for models without classes (autoencoders): loss only
             base = r * per_loss.shape[0]
-            for t in sorted(per_cm):
+            every = fed.engine.LOG_EVERY
+            for t in range(every, per_loss.shape[0] + 1, every):
                 for k, i in enumerate(fed.local):
                     if fed.alive[i]:
                         row = {"Train/Loss": float(per_loss[t - 1, k])}
-                        row.update({f"Train/{name}": v for name, v in per_cm[t][k].items()})
+                        if t in per_cm:
+                            row.update({f"Train/{name}": v for name, v in per_cm[t][k].items()})
                         loggers[i].log_metrics_direct(row, base + t)
         for k, i in enumerate(fed.local):
             # (with the per-step series above, "Train/Loss" is the step axis; the epoch mean goes to TrainEpoch/Loss)

@@ -104,7 +104,8 @@ class ModuleEngine(ShardEngine):
     ``P2PFL_MODULE_VMAP=0``). The per-node loop remains as the fallback and as the oracle of the batched path."""
 
     def __init__(self, spec: ModuleSpec, n_clients: int, device="cpu", batch_size: int = 32, seed: int = 0,
-                 persist_optimizer: bool = False, client_offset: int = 0, batched: Optional[bool] = None):
+                 persist_optimizer: bool = False, client_offset: int = 0, batched: Optional[bool] = None,
+                 log_steps: bool = False):
         self.spec = spec
         self.K = int(n_clients)
         self.device = torch.device(device)
@@ -123,6 +124,12 @@ class ModuleEngine(ShardEngine):
         self.classifier = bool(getattr(self.modules[0], "is_classifier", True))
         self.C = max(int(spec.num_classes), 2)
         self.stats = {ph: PhaseStats.alloc(self.K, self.C, self.device) for ph in PHASES}
+        # per-step Train/* series (ShardEngine._init_step_log). The batched pass of ONE epoch is what gets captured and
+        # replayed, so its steps write epoch-local tables (same addresses every epoch) that are copied into the tables
+        # of the whole fit after each epoch.
+        self._init_step_log(log_steps)
+        self._ep_log = self._ep_cm = None
+        self._ep_row: Dict[int, int] = {}
         for k, m in enumerate(self.modules):
             tensors = dict(m.named_parameters())
             tensors.update(dict(m.named_buffers()))
@@ -373,6 +380,38 @@ class ModuleEngine(ShardEngine):
                 with torch.no_grad():
                     losses, preds = self._vstep(state, xb, yb)
             self._metrics(phase, losses, preds, yb, nb)
+            if train and self._ep_log is not None:
+                pos, st = s // self.B, self.stats[phase]
+                self._ep_log[pos, 0].copy_(st.loss_sum)
+                self._ep_log[pos, 1].copy_(st.count)
+                row = self._ep_row.get(pos)
+                if row is not None:
+                    self._ep_cm[row].copy_(st.confusion)
+
+    def _alloc_epoch_tables(self, epochs: int) -> None:
+        spe = self.steps_per_epoch()
+        if not self._alloc_step_tables(epochs * spe) and self._ep_log is not None:
+            return
+        if not self.log_steps:
+            return
+        if not self.classifier:
+            self._cm_slot = {}                        # loss only: nothing to derive class metrics from
+        self._ep_log = torch.zeros(spe, 2, self.K, device=self.device)
+        self._ep_row = {p: i for i, p in enumerate(sorted({q % spe for q in self._cm_slot}))}
+        self._ep_cm = torch.zeros(max(len(self._ep_row), 1), self.K, self.C, self.C, dtype=torch.int32, device=self.device)
+        if self._graphs:                              # captured training passes do not write the new tables
+            torch.cuda.synchronize(self.device)
+            self._graphs = {k: g for k, g in self._graphs.items() if not k[1]}
+
+    def _collect_epoch_tables(self, e: int) -> None:
+        if self._ep_log is None:
+            return
+        spe = self._ep_log.shape[0]
+        self._step_log[e * spe:(e + 1) * spe].copy_(self._ep_log)
+        for p, row in self._ep_row.items():
+            slot = self._cm_slot.get(e * spe + p)
+            if slot is not None:
+                self._step_cm[slot].copy_(self._ep_cm[row])
 
     def _fit_batched(self, epochs: int, active) -> Dict:
         if self._stack_opt is None or not self.persist_optimizer:
@@ -384,10 +423,12 @@ class ModuleEngine(ShardEngine):
             saved = (inactive, self.params[inactive].clone(), ints)
         perms = self._epoch_perms(epochs).to(self.device).long()
         n = self.train_x.shape[1]
+        self._alloc_epoch_tables(epochs)
         out = {}
         for e in range(epochs):
             self.stats["Train"].zero_(); self.stats["Validation"].zero_()
             self._phase_batched(self.train_x, self.train_y, "Train", True, self._stack_opt, perms[e, :, :n])
+            self._collect_epoch_tables(e)
             if self.val_x is not None:
                 self._phase_batched(self.val_x, self.val_y, "Validation", False)
             out = {"Train": self.stats["Train"].summary(), "Validation": self.stats["Validation"].summary()}
@@ -405,7 +446,7 @@ class ModuleEngine(ShardEngine):
         self._stack_opt = None
         self.opt_steps = 0
 
-    def _run_phase(self, k, x, y, phase, train, optim=None, order=None) -> None:
+    def _run_phase(self, k, x, y, phase, train, optim=None, order=None, step0: int = 0) -> None:
         m, st, C = self.modules[k], self.stats[phase], self.C
         n = x.shape[0]
         for s in range(0, n, self.B):
@@ -432,6 +473,8 @@ class ModuleEngine(ShardEngine):
                 yc = yb.clamp(0, C - 1)
                 st.correct[k] += (pred == yc).sum().to(torch.int32)
                 st.confusion[k].view(-1).index_add_(0, yc * C + pred, torch.ones_like(pred, dtype=torch.int32))
+            if train:
+                self._record_client_step(step0 + s // self.B, k)
 
     def fit(self, epochs, active=None):
         if self.batched:
@@ -448,6 +491,9 @@ class ModuleEngine(ShardEngine):
             self.reset_optimizer()
         perms = self._epoch_perms(epochs).to(self.device).long()
         n = self.train_x.shape[1]
+        self._ep_log = None
+        if self._alloc_step_tables(epochs * self.steps_per_epoch()) and not self.classifier:
+            self._cm_slot = {}
         out = {}
         for e in range(epochs):
             self.stats["Train"].zero_(); self.stats["Validation"].zero_()
@@ -455,7 +501,8 @@ class ModuleEngine(ShardEngine):
                 if active is not None and not bool(active[k]):
                     continue
                 self.modules[k].train()
-                self._run_phase(k, self.train_x[k], self.train_y[k], "Train", True, self.optims[k], perms[e, k, :n])
+                self._run_phase(k, self.train_x[k], self.train_y[k], "Train", True, self.optims[k], perms[e, k, :n],
+                                step0=e * self.steps_per_epoch())
                 if self.val_x is not None:
                     self.modules[k].eval()
                     self._run_phase(k, self.val_x[k], self.val_y[k], "Validation", False)

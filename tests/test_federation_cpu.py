@@ -353,3 +353,26 @@ def test_waiting_node_adopts_the_aggregator_that_finishes_first():
     fed.alive[0] = False                                  # dead but not yet evicted: 1 waits for a model that never comes
     _, adopt = fed._round_structure()
     assert fed.timed_out == [1] and adopt == {2: 3}
+
+
+def test_eager_engine_per_step_series():
+    """log_steps on the CPU engine: per-step loss and the confusion matrix of every 20th step's batch
+    (reference: Train/* per step, every 20 steps - lightninglearner.py:188, mnist/models/mlp.py:33-106)."""
+    from p2pfl_amd.models.specs import get_spec
+    from p2pfl_amd.runtime.engine import EagerEngine
+    spec = get_spec("mnist-mlp")
+    K, n, B = 2, 96, 4
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.randn(K, n, 784, generator=g), torch.randint(0, 10, (K, n), generator=g)
+    eng = EagerEngine(spec, K, "cpu", batch_size=B, seed=3, log_steps=True)
+    eng.init_params()
+    eng.set_data(x, y, x[:, :8], y[:, :8], x[:, :8], y[:, :8])
+    out = eng.fit(2)
+    losses = eng.step_losses()
+    assert losses.shape == (48, K) and bool((losses > 0).all())
+    # the mean of the second epoch's per-step losses is the epoch loss the engine reports
+    assert torch.allclose(losses[24:].mean(0), out["Train"]["loss"].float().cpu(), atol=1e-5)
+    cms = eng.step_confusions()
+    assert sorted(cms) == [20, 40] and all(c.sum(dim=(1, 2)).tolist() == [B, B] for c in cms.values())
+    m = eng.step_metrics()[20]
+    assert len(m) == K and set(m[0]) == {"Accuracy", "Precision", "Recall", "F1Score"}

@@ -96,6 +96,10 @@ def test_launcher_runs_non_spec_families_with_faults_checkpoints_resume(tmp_path
     assert s["nodes"] == 3 and s["rounds"] == 2 and np.isfinite(s["final_test_loss"])
     logs = tmp_path / "logs" / "scen"
     assert "alive False" in open(logs / "participant_2.log").read()
+    # the per-step series of the reference's models (every 20 optimizer steps) for the stock-op families too
+    rows = [r.split(",") for r in open(logs / "metrics" / "participant_0" / "metrics.csv").read().strip().splitlines()[1:]]
+    at20 = {r[2] for r in rows if int(r[1]) == 20}
+    assert "Train/Loss" in at20 and ("Train/F1Score" in at20) == (model != "Autoencoder")
     s2 = run_scenario(cdir, device="cpu", rounds=3, resume=str(logs))
     assert s2["first_round"] == 2 and s2["final_test_loss"] <= s["final_test_loss"] * 1.5 + 1e-3
 
@@ -245,3 +249,31 @@ def test_client_batched_falls_back_when_vmap_cannot_express_the_step():
     out = eng.fit(3)
     assert out["Train"]["count"].tolist() == [8, 8] and not torch.equal(before, eng.params)
     assert (eng.evaluate()["loss"] < l0 * 2.0 + 1e-6).all()
+
+
+@pytest.mark.parametrize("ds,model", [("SYSCALL", "MLP"), ("SYSCALL", "Autoencoder")])
+def test_per_step_series_of_module_families(ds, model, monkeypatch):
+    """log_steps: loss of every optimizer step and (classifiers) the confusion matrix of every 20th step's batch, the
+    same from the vmap path (epoch-local tables written inside the replayed pass) and from the per-node loop.
+    Reference: Train/* logged per step, every 20 steps (lightninglearner.py:188, syscall/models/mlp.py)."""
+    monkeypatch.setenv("P2PFL_MODULE_VMAP_STRICT", "1")
+    monkeypatch.setattr(ModuleEngine, "LOG_EVERY", 4)
+    loop, vm = _pair(ds, model, n=24, B=4, log_steps=True)                 # 6 steps per epoch
+    loop.fit(2); vm.fit(2)
+    assert vm.batched
+    l0, l1 = loop.step_losses(), vm.step_losses()
+    assert l0.shape == l1.shape == (12, 3)
+    assert torch.allclose(l0, l1, atol=1e-4) and (l0 > 0).all()
+    c0, c1 = loop.step_confusions(), vm.step_confusions()
+    if loop.classifier:
+        assert sorted(c0) == sorted(c1) == [4, 8, 12]
+        for t in c0:
+            assert torch.equal(c0[t], c1[t])
+            assert c0[t].sum(dim=(1, 2)).tolist() == [4, 4, 4]            # one batch of four samples per client
+        m = vm.step_metrics()[8][0]
+        assert set(m) == {"Accuracy", "Precision", "Recall", "F1Score"}
+    else:
+        assert c0 == c1 == {} and vm.step_metrics() == {}
+    # a second fit re-uses the tables (and, on a GPU, the captured passes that write them)
+    vm.fit(2)
+    assert vm.step_losses().shape == (12, 3)

@@ -68,6 +68,7 @@ def test_module_engine_graph_replay_matches_eager_batched_passes(ds, model, seg,
     import torch
     from p2pfl_amd.node_start import build_dataset_and_model, build_model
     from p2pfl_amd.runtime.module_engine import ModuleEngine, ModuleSpec
+    monkeypatch.setattr(ModuleEngine, "LOG_EVERY", 2)
     monkeypatch.setenv("P2PFL_MODULE_VMAP_STRICT", "1")
     probe = build_dataset_and_model(ds, model, 0, 20)[0]
     spec = ModuleSpec(f"{ds}-{model}", lambda: build_model(ds, model), probe.num_classes, tuple(probe.input_shape))
@@ -78,7 +79,7 @@ def test_module_engine_graph_replay_matches_eager_batched_passes(ds, model, seg,
     engines = {}
     for graph in ("0", "1"):
         monkeypatch.setenv("P2PFL_MODULE_GRAPH", graph)
-        eng = ModuleEngine(spec, K, "cuda", seed=1, batched=True, batch_size=32)
+        eng = ModuleEngine(spec, K, "cuda", seed=1, batched=True, batch_size=32, log_steps=True)
         for m in eng.modules:
             for mod in m.modules():
                 if isinstance(mod, torch.nn.Dropout):
@@ -96,11 +97,19 @@ def test_module_engine_graph_replay_matches_eager_batched_passes(ds, model, seg,
         assert torch.allclose(res["0"][0], res["1"][0], atol=2e-3, rtol=2e-3), rnd
         assert torch.allclose(res["0"][1], res["1"][1], atol=2e-3, rtol=2e-3), rnd
         assert torch.equal(res["0"][2], res["1"][2])
+        # per-step series written from inside the replayed passes (epoch-local tables, collected after every epoch)
+        l0, l1 = engines["0"].step_losses(), engines["1"].step_losses()
+        assert l0.shape == l1.shape == (6, K) and torch.allclose(l0, l1, atol=2e-3, rtol=2e-3), rnd
     g = engines["1"]
     assert g.use_graph and len(g._graphs) >= 3          # test pass, training epoch, validation pass
     if seg:                                             # 96 samples = 3 steps: two segments per training pass
         assert max(len(v) for v in g._graphs.values()) == 2
     assert torch.equal(g.params[2], engines["0"].params[2])          # the idle node kept its (identical) model
+    if engines["0"].classifier:
+        c0, c1 = engines["0"].step_confusions(), g.step_confusions()
+        assert sorted(c0) == sorted(c1) == [2, 4, 6]
+        for t in c0:                                     # (the idle node trains too and is restored afterwards)
+            assert c1[t].sum(dim=(1, 2)).tolist() == [32] * K
     g.set_data(*data)
     assert not g._graphs                                 # new data: the captured passes are dropped
     g.evaluate(); g.fit(1)

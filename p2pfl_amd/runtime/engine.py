@@ -441,6 +441,7 @@ class HipEngine(ShardEngine):
         # Train/{Accuracy,Precision,Recall,F1Score} series of the reference's models (mnist/models/mlp.py:33-106:
         # torchmetrics on the step's batch, logged every 20 steps)
         self._init_step_log(log_steps)
+        self._in_prepare = False
         if self.device.type != "cuda":
             raise RuntimeError("HipEngine needs a GPU device")
         from ..ops import hip
@@ -1250,16 +1251,14 @@ class HipEngine(ShardEngine):
                 # (the snapshot BEFORE the warm-up stream picks up its dependency on this one: taken after
                 # `s.wait_stream`, the clones raced the warm-up - the class head, whose update is the first thing a step
                 # writes, saw second moments that already contained the warm-up's gradients)
-                snap = (self.params.clone(), self.m.clone(), None if self.v is None else self.v.clone())
+                snap = None if self._in_prepare else self._snapshot_state()   # (prepare() restores its own snapshot)
                 s = torch.cuda.Stream(device=self.device)
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):
                     self._train(1, min(steps, 2), n)
                 torch.cuda.current_stream().wait_stream(s)
                 torch.cuda.synchronize()
-                self.params.copy_(snap[0]); self.m.copy_(snap[1])
-                if self.v is not None:
-                    self.v.copy_(snap[2])
+                self._restore_state(snap)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):   # RCCL's watchdog thread may query events meanwhile
                     self._capturing = True
@@ -1268,9 +1267,7 @@ class HipEngine(ShardEngine):
                     finally:
                         self._capturing = False
                 self._graphs[key] = (g,)
-                self.params.copy_(snap[0]); self.m.copy_(snap[1])
-                if self.v is not None:
-                    self.v.copy_(snap[2])
+                self._restore_state(snap)
             self._graphs[key][0].replay()
         else:
             self._train(epochs, steps, n)
@@ -1290,17 +1287,36 @@ class HipEngine(ShardEngine):
         """Build everything a round needs ahead of time - lazy kernel loading, buffers, the captured training
         and evaluation graphs - by running one round and putting parameters, optimizer state, step and shuffle
         counters back, so the first real round costs what every other round costs."""
-        snap = (self.params.clone(), self.m.clone(), None if self.v is None else self.v.clone(), self.opt_steps,
-                self._perm_calls)
-        self.evaluate()
-        self.fit(epochs)
+        snap, counters = self._snapshot_state(), (self.opt_steps, self._perm_calls)
+        self._in_prepare = True
+        try:
+            self.evaluate()
+            self.fit(epochs)
+        finally:
+            self._in_prepare = False
         self.synchronize()
-        self.params.copy_(snap[0]); self.m.copy_(snap[1])
-        if self.v is not None:
-            self.v.copy_(snap[2])
-        self.opt_steps, self._perm_calls = snap[3], snap[4]
+        self._restore_state(snap)
+        self.opt_steps, self._perm_calls = counters
         for st in self.stats.values():
             st.zero_()
+
+    def _snapshot_state(self):
+        """Copies of parameters and optimizer state (warm-up steps and the prepare() round are undone with them): on the
+        device while a second copy of the state fits beside what a round allocates, else in host memory - a shard sized
+        for the 288 GB of the card (2000 MNIST-CNN nodes: 145 GB of p / m / v) must not need its state twice."""
+        state = [t for t in (self.params, self.m, self.v) if t is not None]
+        need = sum(t.numel() * t.element_size() for t in state)
+        free = torch.cuda.mem_get_info(self.device)[0]
+        cached = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
+        where = self.device if 2 * need < free + cached else torch.device("cpu")
+        return tuple(None if t is None else t.to(where, copy=True) for t in (self.params, self.m, self.v))
+
+    def _restore_state(self, snap) -> None:
+        if snap is None:
+            return
+        for dst, src in zip((self.params, self.m, self.v), snap):
+            if dst is not None:
+                dst.copy_(src)
 
     def _eval_body(self) -> None:
         self.stats["Test"].zero_()

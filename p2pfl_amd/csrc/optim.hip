@@ -9,7 +9,8 @@ namespace {
 
 struct AdamArgs {
     float* p; const float* g; float* m; float* v;
-    long cs;            // row stride (floats) shared by the four slabs
+    long cs;            // row stride (floats) shared by the parameter / moment slabs
+    long g_cs;          // row stride of the gradient slab (the engine's leaves out the layers with fused updates)
     long n4;            // float4 elements per row
     long n4a, skip4;    // two column ranges in one launch: element i >= n4a lives skip4 float4 further on (one range: n4a = n4)
     float lr, beta1, beta2, eps, weight_decay;
@@ -21,7 +22,7 @@ struct AdamArgs {
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     const long row = (long)blockIdx.y * a.cs;
     float4* p = reinterpret_cast<float4*>(a.p + row);
-    const float4* g = reinterpret_cast<const float4*>(a.g + row);
+    const float4* g = reinterpret_cast<const float4*>(a.g + (long)blockIdx.y * a.g_cs);
     float4* m = reinterpret_cast<float4*>(a.m + row);
     float4* v = reinterpret_cast<float4*>(a.v + row);
     const float inv_bc1 = a.bc ? a.bc[0] : a.inv_bc1;
@@ -46,14 +47,14 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
 
 struct SgdArgs {
     float* p; const float* g; float* buf;
-    long cs, n4;
+    long cs, g_cs, n4;
     float lr, momentum, weight_decay;
 };
 
 __global__ __launch_bounds__(256) void sgdm_kernel(SgdArgs a) {
     const long row = (long)blockIdx.y * a.cs;
     float4* p = reinterpret_cast<float4*>(a.p + row);
-    const float4* g = reinterpret_cast<const float4*>(a.g + row);
+    const float4* g = reinterpret_cast<const float4*>(a.g + (long)blockIdx.y * a.g_cs);
     float4* b = reinterpret_cast<float4*>(a.buf + row);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (long)gridDim.x * 256) {
         float4 pv = p[i], gv = g[i], bv = b[i];
@@ -77,15 +78,15 @@ inline int grid_x(long n4, int K) {
 
 }  // namespace
 
-P2PFL_API int p2pfl_adam_step(float* p, const float* g, float* m, float* v, long cs, long n, int K,
+P2PFL_API int p2pfl_adam_step(float* p, const float* g, float* m, float* v, long cs, long g_cs, long n, int K,
                               float lr, float beta1, float beta2, float eps, float weight_decay,
                               int t, const float* bc, hipStream_t stream) {
     if (K <= 0 || n <= 0 || t <= 0) return -1;
-    if ((n & 3) || (cs & 3) || ((uintptr_t)p & 15) || ((uintptr_t)g & 15) || ((uintptr_t)m & 15) ||
+    if ((n & 3) || (cs & 3) || (g_cs & 3) || ((uintptr_t)p & 15) || ((uintptr_t)g & 15) || ((uintptr_t)m & 15) ||
         ((uintptr_t)v & 15))
         return -2;
     const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
-    AdamArgs a{p, g, m, v, cs, n / 4, n / 4, 0, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
+    AdamArgs a{p, g, m, v, cs, g_cs, n / 4, n / 4, 0, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
                (float)(1.0 / sqrt(bc2)), bc};
     hipLaunchKernelGGL(adam_kernel, dim3(grid_x(n / 4, K), K), dim3(256), 0, stream, a);
     P2PFL_RETURN_LAST_ERROR();
@@ -104,18 +105,18 @@ P2PFL_API int p2pfl_adam_step2(float* p, const float* g, float* m, float* v, lon
         return -2;
     if (n0 + gap + n1 > cs) return -3;
     const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
-    AdamArgs a{p, g, m, v, cs, (n0 + n1) / 4, n0 / 4, gap / 4, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
+    AdamArgs a{p, g, m, v, cs, cs, (n0 + n1) / 4, n0 / 4, gap / 4, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
                (float)(1.0 / sqrt(bc2)), bc};
     hipLaunchKernelGGL(adam_kernel, dim3(grid_x((n0 + n1) / 4, K), K), dim3(256), 0, stream, a);
     P2PFL_RETURN_LAST_ERROR();
 }
 
-P2PFL_API int p2pfl_sgdm_step(float* p, const float* g, float* buf, long cs, long n, int K, float lr,
+P2PFL_API int p2pfl_sgdm_step(float* p, const float* g, float* buf, long cs, long g_cs, long n, int K, float lr,
                               float momentum, float weight_decay, hipStream_t stream) {
     if (K <= 0 || n <= 0) return -1;
-    if ((n & 3) || (cs & 3) || ((uintptr_t)p & 15) || ((uintptr_t)g & 15) || ((uintptr_t)buf & 15))
+    if ((n & 3) || (cs & 3) || (g_cs & 3) || ((uintptr_t)p & 15) || ((uintptr_t)g & 15) || ((uintptr_t)buf & 15))
         return -2;
-    SgdArgs a{p, g, buf, cs, n / 4, lr, momentum, weight_decay};
+    SgdArgs a{p, g, buf, cs, g_cs, n / 4, lr, momentum, weight_decay};
     hipLaunchKernelGGL(sgdm_kernel, dim3(grid_x(n / 4, K), K), dim3(256), 0, stream, a);
     P2PFL_RETURN_LAST_ERROR();
 }

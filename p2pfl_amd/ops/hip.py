@@ -137,9 +137,9 @@ class _Sig:
     p2pfl_conv2_dgrad = [P, L, P, L, P, L, P, L, I, I, I, I, I, I, I, P]
     p2pfl_softmax_ce = [P, L, P, L, P, L, P, L, P, P, P, P, P, L, I, I, I, P]
     p2pfl_zero_rows = [P, L, I, I, P]
-    p2pfl_adam_step = [P, P, P, P, L, L, I, F, F, F, F, F, I, P, P]
+    p2pfl_adam_step = [P, P, P, P, L, L, L, I, F, F, F, F, F, I, P, P]
     p2pfl_adam_step2 = [P, P, P, P, L, L, L, L, I, F, F, F, F, F, I, P, P]
-    p2pfl_sgdm_step = [P, P, P, L, L, I, F, F, F, P]
+    p2pfl_sgdm_step = [P, P, P, L, L, L, I, F, F, F, P]
     p2pfl_fedavg = [P, L, I, P, L, P, L, P, P, P, P, P, I, L, P]
     p2pfl_fedavg_inplace = [P, L, I, P, L, I, P, P, P, P, P, I, L, P]
     p2pfl_fedavg_inplace_chunk = [I]
@@ -538,14 +538,14 @@ def zero_rows(t) -> None:
 
 # ----------------------------------------------------------------------------- optimizers
 def adam_step(p, g, m, v, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, t: int, bc=None) -> None:
-    """One Adam step over [K, P] slabs that share one row stride.
+    """One Adam step over [K, P] slabs; p / m / v share one row stride, the gradient slab may have its own.
 
     ``bc``: optional device tensor [2] = (1/(1-beta1^t), 1/sqrt(1-beta2^t)) read by the kernel at
     run time instead of the host-computed scalars (lets a captured graph be replayed for any t)."""
     K, n = p.shape
     cs = p.stride(0)
-    assert g.stride(0) == cs and m.stride(0) == cs and v.stride(0) == cs and g.shape == p.shape
-    _chk(load().p2pfl_adam_step(_t(p).data_ptr(), _t(g).data_ptr(), _t(m).data_ptr(), _t(v).data_ptr(), cs, n, K,
+    assert m.stride(0) == cs and v.stride(0) == cs and g.shape == p.shape and g.stride(1) == 1
+    _chk(load().p2pfl_adam_step(_t(p).data_ptr(), _t(g).data_ptr(), _t(m).data_ptr(), _t(v).data_ptr(), cs, g.stride(0), n, K,
                                 lr, beta1, beta2, eps, weight_decay, t,
                                 None if bc is None else _t(bc).data_ptr(), _stream()), "adam_step")
 
@@ -566,8 +566,8 @@ def adam_step_ranges(p, g, m, v, ranges, *, lr, beta1=0.9, beta2=0.999, eps=1e-8
 def sgdm_step(p, g, buf, *, lr, momentum=0.9, weight_decay=0.0) -> None:
     K, n = p.shape
     cs = p.stride(0)
-    assert g.stride(0) == cs and buf.stride(0) == cs and g.shape == p.shape
-    _chk(load().p2pfl_sgdm_step(_t(p).data_ptr(), _t(g).data_ptr(), _t(buf).data_ptr(), cs, n, K, lr, momentum,
+    assert buf.stride(0) == cs and g.shape == p.shape and g.stride(1) == 1
+    _chk(load().p2pfl_sgdm_step(_t(p).data_ptr(), _t(g).data_ptr(), _t(buf).data_ptr(), cs, g.stride(0), n, K, lr, momentum,
                                 weight_decay, _stream()), "sgdm_step")
 
 

@@ -40,7 +40,7 @@ def test_first_step_gradients_match_autograd(name, precision):
         loss.backward()
         assert abs(h.stats["Train"].loss_sum[k].item() / B - loss.item()) < (1e-5 if f32 else 2e-2) * max(1.0, loss.item())
         for pname, p in m.named_parameters():
-            g = h.layout.view(h.grads, pname)[k]
+            g = h.grad_view(pname)[k]
             # fp32 (the default policy): whole-network gradients agree with autograd to round-off.
             # bf16 operand rounding compounds through the layers and flips ReLU/pool decisions of
             # near-zero units, so there the deepest gradients are compared in the Frobenius norm / by angle

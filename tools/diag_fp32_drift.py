@@ -19,7 +19,7 @@ for k in range(1):
     yb = e.train_y[k][sidx[k].long()].long()
     m.criterion(m(xb), yb).backward()
     for pname, p in m.named_parameters():
-        g = h.layout.view(h.grads, pname)[k]
+        g = h.grad_view(pname)[k]
         ref = p.grad
         d = (g - ref).abs()
         sign_flip = ((g * ref) < 0).float().mean().item()

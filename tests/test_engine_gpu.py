@@ -154,6 +154,47 @@ def test_prepare_leaves_no_trace():
     assert torch.equal(res[0], res[1])
 
 
+def test_prepare_keeps_its_snapshot_in_host_memory_when_the_card_is_full(monkeypatch):
+    """A shard sized for the card (2000 MNIST-CNN nodes = 145 GB of weights and moments) cannot hold a second copy of
+    its state: prepare() then keeps its one snapshot on the host - and fit() takes none of its own inside prepare()."""
+    from p2pfl_amd.datasets.synthetic import synthetic_shards
+    from p2pfl_amd.models.specs import get_spec
+    from p2pfl_amd.runtime.engine import HipEngine
+    spec = get_spec("mnist-cnn")
+    data = synthetic_shards(3, 64, 16, 32, spec.num_classes, seed=5, device="cuda")
+    h = HipEngine(spec, 3, "cuda", seed=7)
+    h.init_params(identical=False)
+    h.set_data(*data)
+    total = torch.cuda.mem_get_info()[1]
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a, **k: (0, total))
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda *a, **k: 0)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda *a, **k: 0)
+    where = []
+    real = h._snapshot_state
+    monkeypatch.setattr(h, "_snapshot_state", lambda: (where.append(1), real())[1])
+    snap = real()
+    assert all(t is None or t.device.type == "cpu" for t in snap)
+    p0, m0 = h.params.clone(), h.m.clone()
+    h.prepare(1)
+    assert where == [1], "one snapshot per prepare(): the capture inside fit() must not take another"
+    assert torch.equal(h.params, p0) and torch.equal(h.m, m0) and h.opt_steps == 0
+
+
+def test_gradient_slab_leaves_out_the_layers_with_fused_updates():
+    """The fused wgrad+Adam layer never stores its gradient: no columns for it in the gradient slab (96 % of a row)."""
+    spec, h, _ = _pair("mnist-cnn")
+    l1 = spec.layers[2]
+    assert 2 in h._fused and h.grads.shape[1] < h.layout.row_stride // 20
+    with pytest.raises(KeyError):
+        h.grad_view(l1.weight)
+    assert h._gw(l1) == (None, None)
+    gw, gb = h._gw(spec.layers[3])
+    assert gw.shape == (h.K, 10, 2048) and gb.shape == (h.K, 10)
+    assert h.grad_view(spec.layers[0].weight).data_ptr() == h.grads.data_ptr()
+    _, h2, _ = _pair("mnist-cnn", fuse=False)
+    assert h2.grads.shape[1] == h2.layout.row_stride
+
+
 def test_pipelined_schedule_matches_single_stream():
     """Two-stream schedule (conv kernels under the fused wgrad+Adam; graph branches) == the in-order schedule
     and the same two-stream schedule launched eagerly (use_graph=False)."""

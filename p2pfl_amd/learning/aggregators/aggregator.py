@@ -119,6 +119,23 @@ class Aggregator(Observable):
             self.notify(Events.AGGREGATION_FINISHED_EVENT, result)
             done.set()
 
+    def run(self):
+        """The reference's thread body (aggregator.py:40-74: wait for every model of the train set or for
+        AGGREGATION_TIMEOUT, aggregate what is there, notify AGGREGATION_FINISHED). Here a waiter thread is armed by
+        the first model of a round; calling ``run()`` does the same wait synchronously for the current round - for
+        code that drove the reference class as ``aggregator.run()`` / a started thread."""
+        with self._lock:
+            if self._armed:                    # this round already has its waiter: just wait for its delivery
+                done = self._done
+                gen = None
+            else:
+                self._armed = True
+                gen, ready, done = self._generation, self._ready, self._done
+        if gen is None:
+            done.wait(self._timeout() + 5.0)
+        else:
+            self._wait_and_aggregate(gen, ready, done)
+
     def wait_aggregation(self, timeout: Optional[float] = None) -> bool:
         """Block until this round's result was delivered (True) or ``timeout`` elapsed."""
         return self._done.wait(timeout if timeout is not None else self._timeout() + 5.0)

@@ -236,6 +236,11 @@ class NodeConnection(threading.Thread, Observable):
             self.__models_aggregated = list(set(models + self.__models_aggregated))
             self.__fresh = True
 
+    def add_processed_messages(self, msgs):
+        """Message ids this connection must treat as seen (reference node_connection.py:259-269: gossiped
+        messages are marked on every connection of the node so none of them relays a duplicate)."""
+        self.comm_protocol.add_processed_messages(list(msgs))
+
     def payload_round(self):
         """Round a payload arriving NOW on this link belongs to. PARAMS frames carry no round number,
         but the link is ordered: a peer announces MODELS_READY r when it holds round r's model and

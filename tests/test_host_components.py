@@ -216,6 +216,19 @@ def test_aggregator_bookkeeping_partial_waiting_timeout():
     n = len(obs.events)
     agg.add_model(_sd(1), ["n1"], 1)
     assert len(obs.events) == n
+    # run(): the reference's thread body (aggregator.py:40-74), synchronous here - waits out the timeout for the
+    # missing model, aggregates what is there and notifies once; on an armed round it only waits for the delivery
+    agg.clear()
+    agg.set_nodes_to_aggregate(["n1", "n2"])
+    n = len(obs.events)
+    t0 = time.time()
+    agg.run()                                                       # nothing arrived: times out, nothing to aggregate
+    assert 0.4 < time.time() - t0 < 3 and obs.events[n:] == [(Events.AGGREGATION_FINISHED_EVENT, None)]
+    agg.clear()
+    agg.set_nodes_to_aggregate(["n1"])
+    agg.add_model(_sd(5), ["n1"], 2)
+    agg.run()
+    assert torch.allclose(obs.events[-1][1]["w"], torch.full((2, 3), 5.0))
 
 
 def test_macro_metrics_match_sklearn():

@@ -43,7 +43,36 @@ class Mender:
         self.token = r.text
         return self.token
 
-    renew_token = get_token
+    def renew_token(self):
+        """Log in again whatever token is held (reference mender.py:22-32)."""
+        self.token = None
+        return self.get_token()
+
+    @staticmethod
+    def generate_artifact(type_artifact, artifact_name, device_type, file_path):
+        """Write ``<artifact_name>.mender`` with the ``mender-artifact`` tool (reference mender.py:34-36; the tool is
+        not part of this image: a missing executable is reported, not ignored)."""
+        import shutil
+        import subprocess
+        tool = shutil.which("mender-artifact")
+        if tool is None:
+            raise FileNotFoundError("mender-artifact is not installed")
+        out = f"{artifact_name}.mender"
+        subprocess.run([tool, "write", "module-image", "-T", str(type_artifact), "-n", str(artifact_name),
+                        "-t", str(device_type), "-o", out, "-f", str(file_path)], check=True)
+        return out
+
+    def get_my_info(self):
+        r = self._session().get(self._url("/api/management/v1/useradm/users/me"), headers=self._headers(),
+                                timeout=self.timeout)
+        r.raise_for_status()
+        return r.json()
+
+    def get_info_deployment(self, deployment_id):
+        r = self._session().get(self._url(f"/api/management/v1/deployments/deployments/{deployment_id}"),
+                                headers=self._headers(), timeout=self.timeout)
+        r.raise_for_status()
+        return r.json()
 
     # ------------------------------------------------------------------ API
     def get_artifacts(self):

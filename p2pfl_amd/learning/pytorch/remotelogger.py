@@ -213,6 +213,25 @@ class FedstellarWBLogger(_FederatedStepping):
         self._init_kwargs = dict(name=name, project=project, group=group, dir=save_dir, id=version or id,
                                  resume="allow", mode="offline" if offline else None, **kwargs)
 
+    def __getstate__(self):
+        """Picklable: the run handle (and the imported module) stay behind; the run's id travels so the copy re-attaches
+        to the same run on first use (reference remotelogger.py:108-118)."""
+        state = self.__dict__.copy()
+        if self._run is not None:
+            state["_init_kwargs"] = dict(self._init_kwargs, id=getattr(self._run, "id", None) or self._init_kwargs.get("id"))
+        state["_run"] = None
+        state["_wandb"] = None
+        state["_checkpoint_callback"] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        try:
+            import wandb
+            self._wandb = wandb
+        except ImportError:
+            self._wandb = None
+
     # ------------------------------------------------------------------ run handle
     @property
     def experiment(self):

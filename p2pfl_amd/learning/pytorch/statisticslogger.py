@@ -190,12 +190,26 @@ class _FederatedStepping:
 class FedstellarLogger(_FederatedStepping):
     """TensorBoard logger: ``<save_dir>/<name>/<version>/events.out.tfevents.*``."""
 
-    def __init__(self, save_dir, name="default", version=None, log_graph=False, **kwargs):
+    def __init__(self, save_dir, name="default", version=None, log_graph=False, sub_dir=None, **kwargs):
         super().__init__()
-        self.save_dir, self.name_, self.version_ = save_dir, name, version
-        self.log_dir = os.path.join(save_dir, name or "", str(version) if version is not None else "version_0")
+        self.save_dir, self.name_, self.version_ = os.fspath(save_dir), name or "", version
+        self.sub_dir = None if sub_dir is None else os.fspath(sub_dir)
         self._writer = None
         self.hparams = {}
+
+    # directory layout of the reference logger (statisticslogger.py:63-88): <save_dir>/<name>/<version>[/<sub_dir>];
+    # an integer (or missing) version becomes "version_<n>", a missing one the next free n
+    @property
+    def root_dir(self) -> str:
+        return os.path.join(self.save_dir, self.name)
+
+    @property
+    def log_dir(self) -> str:
+        v = self.version
+        d = os.path.join(self.root_dir, v if isinstance(v, str) else f"version_{v}")
+        if self.sub_dir:
+            d = os.path.join(d, self.sub_dir)
+        return os.path.expanduser(os.path.expandvars(d))
 
     @property
     def experiment(self) -> _EventWriter:
@@ -209,7 +223,43 @@ class FedstellarLogger(_FederatedStepping):
 
     @property
     def version(self):
+        if self.version_ is None:
+            self.version_ = self._get_next_version()
         return self.version_
+
+    def _get_next_version(self) -> int:
+        """One more than the highest ``version_<n>`` directory under ``root_dir`` (0 when there is none)."""
+        try:
+            names = os.listdir(self.root_dir)
+        except OSError:
+            return 0
+        seen = [int(n.split("_", 1)[1]) for n in names
+                if n.startswith("version_") and n.split("_", 1)[1].isdigit() and os.path.isdir(os.path.join(self.root_dir, n))]
+        return max(seen) + 1 if seen else 0
+
+    @staticmethod
+    def _sanitize_params(params) -> dict:
+        """Hyper-parameters as plain values: arrays / tensors with more than one dimension are logged as text."""
+        import numpy as np
+        out = {}
+        for k, v in dict(params or {}).items():
+            if isinstance(v, np.ndarray) or (hasattr(v, "ndim") and hasattr(v, "shape")):
+                if getattr(v, "ndim", 0) > 1:
+                    v = str(v)
+                elif getattr(v, "ndim", 0) == 0:
+                    v = v.item()
+                else:
+                    v = [x.item() if hasattr(x, "item") else x for x in v]
+            elif callable(v):
+                v = getattr(v, "__name__", repr(v))
+            out[str(k)] = v
+        return out
+
+    def __getstate__(self):
+        """Picklable (a learner travels to worker processes with its logger): the open event file stays behind."""
+        state = self.__dict__.copy()
+        state["_writer"] = None
+        return state
 
     def log_metrics(self, metrics: Dict[str, float], step: Optional[int] = None):
         s = self._step(step)
@@ -225,7 +275,7 @@ class FedstellarLogger(_FederatedStepping):
             self.experiment.add_scalar(k, float(v), int(step))
 
     def log_hyperparams(self, params, metrics=None):
-        self.hparams.update(dict(params) if params else {})
+        self.hparams.update(self._sanitize_params(params))
         os.makedirs(self.log_dir, exist_ok=True)
         with open(os.path.join(self.log_dir, "hparams.yaml"), "w") as f:
             for k, v in self.hparams.items():

@@ -81,6 +81,13 @@ def test_mender_client_requests(monkeypatch):
     body = json.loads(calls[-1][2]["data"])
     assert body == {"artifact_name": "art", "devices": ["dev1"], "name": "art-dev1"}
     assert m.deploy_artifact_list("art", ["a", "b"]) == 201 and len(calls) == 5     # token is cached
+    assert m.get_my_info() == [{"id": "dev1"}] and calls[-1][1].endswith("/useradm/users/me")
+    assert m.get_info_deployment("d7") == [{"id": "dev1"}] and calls[-1][1].endswith("/deployments/deployments/d7")
+    n = len(calls)
+    assert m.renew_token() == "jwt-token" and len(calls) == n + 1 and calls[-1][0] == "POST"     # logs in again
+    monkeypatch.setattr("shutil.which", lambda name: None)
+    with pytest.raises(FileNotFoundError):
+        Mender.generate_artifact("single-file", "art", "raspberrypi4", "/tmp/x")
     with pytest.raises(RuntimeError):
         Mender(server="", token="t").get_artifacts()
     # credentials come from the environment, never from the repository

@@ -153,3 +153,42 @@ def test_wandb_present_path_calls_the_sdk(tmp_path, monkeypatch):
     n_init = [c[0] for c in calls].count("init")
     lg2 = m.FedstellarWBLogger(project="proj", save_dir=str(tmp_path))
     assert lg2.experiment is fake.run and [c[0] for c in calls].count("init") == n_init
+
+
+def test_tensorboard_logger_directory_layout_versions_and_pickling(tmp_path):
+    """Layout and auto-versioning of the reference logger (statisticslogger.py:63-88,207-233): <save_dir>/<name>/
+    version_<n>[/<sub_dir>], the next free n when no version is given; the logger pickles without its open file."""
+    import pickle
+
+    import numpy as np
+    from p2pfl_amd.learning.pytorch.statisticslogger import FedstellarLogger, read_event_file
+    a = FedstellarLogger(str(tmp_path), name="run")
+    assert a.root_dir == str(tmp_path / "run") and a.version == 0 and a.log_dir == str(tmp_path / "run" / "version_0")
+    a.log_metrics({"Test/Loss": 1.0}, step=1)
+    a.finalize("success")
+    b = FedstellarLogger(str(tmp_path), name="run", sub_dir="fold1")
+    assert b.version == 1 and b.log_dir == str(tmp_path / "run" / "version_1" / "fold1") and b.sub_dir == "fold1"
+    b.log_hyperparams({"lr": np.float32(0.5), "w": np.zeros((2, 2)), "steps": np.arange(3)})
+    assert b.hparams["lr"] == 0.5 and isinstance(b.hparams["w"], str) and b.hparams["steps"] == [0, 1, 2]
+    b.log_metrics({"Test/Loss": 2.0}, step=1)
+    c = pickle.loads(pickle.dumps(b))                     # the open event file is not part of the state
+    assert c._writer is None and c.log_dir == b.log_dir and c.global_step == b.global_step
+    b.finalize("success")
+    files = [f for f in (tmp_path / "run" / "version_1" / "fold1").iterdir() if "tfevents" in f.name]
+    assert len(files) == 1 and read_event_file(str(files[0]))["Test/Loss"][0][1] == 2.0
+    named = FedstellarLogger(str(tmp_path), name="metrics", version="participant_3")
+    assert named.log_dir == str(tmp_path / "metrics" / "participant_3")
+
+
+def test_wb_logger_pickles_and_reattaches_to_its_run(tmp_path):
+    """reference remotelogger.py:108-118: the logger pickles without its run handle and keeps the run id."""
+    import pickle
+    from p2pfl_amd.learning.pytorch.remotelogger import FedstellarWBLogger
+    lg = FedstellarWBLogger(name="n0", save_dir=str(tmp_path), project="proj", group="g", offline=True)
+    lg.log_metrics({"Test/Loss": 0.5}, step=1)
+    rid = lg.version
+    copy = pickle.loads(pickle.dumps(lg))
+    assert copy._run is None and copy.version == rid and copy.global_step == lg.global_step
+    copy.log_metrics({"Test/Loss": 0.25}, step=2)        # first use re-opens the SAME run directory
+    assert copy.version == rid
+    lg.finalize("success"); copy.finalize("success")

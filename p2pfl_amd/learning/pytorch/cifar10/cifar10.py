@@ -30,14 +30,51 @@ class CIFAR10DataModule(FederatedDataModule):
     synthetic = False
 
     def __init__(self, sub_id=0, number_sub=1, batch_size=32, num_workers=4, val_percent=0.1, iid=True,
-                 root_dir=None, seed=0):
+                 root_dir=None, seed=0, normalization="cifar10", loading="torchvision"):
         super().__init__(sub_id, number_sub, batch_size, num_workers, val_percent, iid, seed)
+        if loading != "torchvision":
+            raise NotImplementedError(loading)              # as in the reference (cifar10.py:55-58)
+        self.normalization, self.loading = normalization, loading
+        stats = self.set_normalization(normalization)
+        self.mean, self.std = stats["mean"], stats["std"]
+        self.root_dir = root_dir or os.path.join(os.getcwd(), "data")
         cls = CIFAR10DataModule
         with LOAD_LOCK:
             if cls.cifar10_train is None:
-                cls._load(root_dir or os.path.join(os.getcwd(), "data"))
+                cls._load(self.root_dir)
         self._install(*cls.cifar10_train, *cls.cifar10_val, drop_val=True)
+        if normalization != "cifar10":                      # the cached arrays carry the CIFAR-10 statistics
+            m2, s2 = torch.tensor(self.mean).view(1, 3, 1, 1), torch.tensor(self.std).view(1, 3, 1, 1)
+            renorm = lambda t: (((t.reshape(-1, 3, 32, 32) * STD + MEAN) - m2) / s2).reshape(len(t), -1).contiguous()
+            self.train_x, self.test_x = renorm(self.train_x), renorm(self.test_x)
         self.val_x, self.val_y = self.test_x, self.test_y   # reference: val loader == test loader
+
+    @staticmethod
+    def set_normalization(normalization):
+        """Channel statistics by name (reference cifar10.py:32-45)."""
+        if normalization == "cifar10":
+            return {"mean": (0.4914, 0.4822, 0.4465), "std": (0.2470, 0.2435, 0.2616)}
+        if normalization == "imagenet":
+            return {"mean": (0.485, 0.456, 0.406), "std": (0.229, 0.224, 0.225)}
+        raise NotImplementedError(normalization)
+
+    def get_dataset(self, train, transform=None, download=False):
+        """The WHOLE (unpartitioned) split as a dataset of normalised ``[3, 32, 32]`` tensors and labels (reference
+        cifar10.py:47-59 hands out torchvision's CIFAR10; nothing is downloaded here - ``cifar10.npz`` under
+        ``root_dir`` or the synthetic stand-in, see the module docstring). ``transform``: callable applied per sample."""
+        x, y = CIFAR10DataModule.cifar10_train if train else CIFAR10DataModule.cifar10_val
+        ds = torch.utils.data.TensorDataset(x.reshape(len(x), 3, 32, 32), y)
+        if transform is None:
+            return ds
+
+        class _Mapped(torch.utils.data.Dataset):
+            def __len__(self_):
+                return len(ds)
+
+            def __getitem__(self_, i):
+                xi, yi = ds[i]
+                return transform(xi), yi
+        return _Mapped()
 
     @classmethod
     def _load(cls, root):

@@ -89,6 +89,108 @@ class FederatedDataModule:
         return self._loader(self.test_x, self.test_y, False)
 
 
+class ArchiveDataset(torch.utils.data.Dataset):
+    """Dataset OBJECT of the reference's data files (``FEMNIST`` / ``SYSCALL`` / ``WADI`` classes of
+    femnist/femnist.py:24-82, syscall/syscall.py:21-120, wadi/wadi.py:20-60): ``data`` / ``targets`` tensors of the
+    train or test split read from ``<root_dir>/<FOLDER>/...``, indexable as ``(sample, int(label))`` with optional
+    transforms. Missing files: ``download=True`` fetches ``download_link`` (checksum-verified when ``file_md5`` is set,
+    archive members confined to the raw directory) and runs :meth:`process`; otherwise ``RuntimeError`` like the
+    reference. The data MODULES of this package read the same files (and fall back to synthetic data without them)."""
+
+    FOLDER = ""
+    download_link = ""
+    file_md5 = None
+
+    def __init__(self, sub_id=0, number_sub=1, root_dir=None, train=True, transform=None, target_transform=None,
+                 download=False):
+        self.sub_id, self.number_sub = sub_id, number_sub
+        self.root = root_dir if root_dir is not None else "./data"
+        self.train, self.transform, self.target_transform, self.download = train, transform, target_transform, download
+        if not self._present():
+            if not download:
+                raise RuntimeError("Dataset not found, set parameter download=True to download")
+            self.dataset_download()
+            self.process()
+        self.data, self.targets = self._read(train)
+
+    # -- to be provided by the dataset ------------------------------------------------------------------------
+    def _files(self):
+        """(train file(s), test file(s)) that must exist under ``self.base``."""
+        raise NotImplementedError
+
+    def _read(self, train):
+        raise NotImplementedError
+
+    def process(self):
+        """raw -> processed files (nothing to do for archives that ship processed files)."""
+
+    # -- common -----------------------------------------------------------------------------------------------
+    @property
+    def base(self):
+        import os
+        return os.path.join(self.root, self.FOLDER)
+
+    def _present(self):
+        import os
+        return all(os.path.exists(f) for group in self._files() for f in group)
+
+    def dataset_download(self):
+        """Fetch ``download_link`` into ``<base>/raw`` and unpack it there (tar / zip; plain files are kept as they
+        are). Any URL scheme of ``urllib`` works, ``file://`` included."""
+        import hashlib
+        import os
+        import shutil
+        import tarfile
+        import urllib.request
+        import zipfile
+        if not self.download_link or "XXXX" in self.download_link:
+            raise RuntimeError(f"{type(self).__name__}: no download location is published for this dataset; "
+                               f"place its files under {self.base}")
+        raw = os.path.join(self.base, "raw")
+        os.makedirs(raw, exist_ok=True)
+        os.makedirs(os.path.join(self.base, "processed"), exist_ok=True)
+        dst = os.path.join(raw, self.download_link.rstrip("/").split("/")[-1])
+        if not os.path.exists(dst):
+            with urllib.request.urlopen(self.download_link) as r, open(dst + ".part", "wb") as f:
+                shutil.copyfileobj(r, f)
+            os.replace(dst + ".part", dst)
+        if self.file_md5:
+            h = hashlib.md5()
+            with open(dst, "rb") as f:
+                for chunk in iter(lambda: f.read(1 << 20), b""):
+                    h.update(chunk)
+            if h.hexdigest() != self.file_md5:
+                os.remove(dst)
+                raise RuntimeError(f"{dst}: checksum mismatch")
+        inside = lambda name: os.path.realpath(os.path.join(raw, name)).startswith(os.path.realpath(raw) + os.sep)
+        if tarfile.is_tarfile(dst):
+            with tarfile.open(dst) as t:
+                members = [m for m in t.getmembers() if (m.isfile() or m.isdir()) and inside(m.name)]
+                t.extractall(raw, members=members)
+        elif zipfile.is_zipfile(dst):
+            with zipfile.ZipFile(dst) as z:
+                z.extractall(raw, members=[n for n in z.namelist() if inside(n)])
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, index):
+        x, target = self.data[index], int(self.targets[index])
+        if self.transform is not None:
+            x = self.transform(x)
+        if self.target_transform is not None:
+            target = self.target_transform(target)
+        return x, target
+
+
+def sort_dataset(dataset):
+    """Order a dataset object by label in place (the reference's non-IID preparation, syscall/syscall.py:115-119)."""
+    order = torch.sort(dataset.targets, stable=True)[1]
+    dataset.targets = dataset.targets[order]
+    dataset.data = dataset.data[order]
+    return dataset
+
+
 def synthetic_classification(n_train: int, n_test: int, features: int, num_classes: int, seed: int,
                              noise: float = 0.35, binary_images: bool = True):
     """Deterministic learnable stand-in for a dataset that cannot be downloaded (no network)."""

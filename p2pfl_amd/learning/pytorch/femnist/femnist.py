@@ -15,7 +15,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from ..datamodule import FederatedDataModule, synthetic_classification, LOAD_LOCK
+from ..datamodule import ArchiveDataset, FederatedDataModule, synthetic_classification, LOAD_LOCK
 
 
 def femnist_transform(x: torch.Tensor, contrast_jitter: bool = False, generator=None) -> torch.Tensor:
@@ -29,6 +29,30 @@ def femnist_transform(x: torch.Tensor, contrast_jitter: bool = False, generator=
         mean = x.mean(dim=(1, 2, 3), keepdim=True)
         x = ((x - mean) * f + mean).clamp_(0, 1)
     return ((x - 0.1307) / 0.3081).reshape(len(x), -1)
+
+
+class FEMNIST(ArchiveDataset):
+    """LEAF FEMNIST as a dataset object (reference femnist/femnist.py:24-82): ``processed/femnist_{train,test}.pt``
+    = ``(data [N,28,28], targets [N])``; the archive ships them processed."""
+    FOLDER = "FEMNIST"
+    download_link = "https://media.githubusercontent.com/media/GwenLegate/femnist-dataset-PyTorch/main/femnist.tar.gz"
+    file_md5 = "60433bc62a9bff266244189ad497e2d7"
+
+    def _files(self):
+        pr = os.path.join(self.base, "processed")
+        return [os.path.join(pr, "femnist_train.pt")], [os.path.join(pr, "femnist_test.pt")]
+
+    def process(self):
+        import shutil
+        for name in ("femnist_train.pt", "femnist_test.pt"):
+            for dirpath, _, files in os.walk(os.path.join(self.base, "raw")):
+                if name in files:
+                    shutil.move(os.path.join(dirpath, name), os.path.join(self.base, "processed", name))
+                    break
+
+    def _read(self, train):
+        data, targets = torch.load(self._files()[0 if train else 1][0], weights_only=True)[:2]
+        return data, targets
 
 
 class FEMNISTDataModule(FederatedDataModule):
@@ -50,8 +74,13 @@ class FEMNISTDataModule(FederatedDataModule):
     @classmethod
     def _load(cls, root, contrast_jitter):
         tr, te = os.path.join(root, "femnist_train.pt"), os.path.join(root, "femnist_test.pt")
+        if not os.path.exists(tr):             # the reference's layout: <root_dir>/FEMNIST/processed/femnist_*.pt
+            for sub in ("processed", os.path.join("FEMNIST", "processed")):
+                if os.path.exists(os.path.join(root, sub, "femnist_train.pt")):
+                    tr, te = os.path.join(root, sub, "femnist_train.pt"), os.path.join(root, sub, "femnist_test.pt")
+                    break
         if os.path.exists(tr) and os.path.exists(te):
-            (tx, ty), (ex, ey) = torch.load(tr, weights_only=True), torch.load(te, weights_only=True)
+            (tx, ty), (ex, ey) = torch.load(tr, weights_only=True)[:2], torch.load(te, weights_only=True)[:2]
             tx, ex = tx.float(), ex.float()
             if tx.max() > 1.5:
                 tx, ex = tx / 255.0, ex / 255.0

@@ -183,11 +183,26 @@ class LightningLearner(NodeLearner):
         return out
 
     # ------------------------------------------------------------------ generic autograd loop
+    _STEP_HOOK = {"Train": "training_step", "Validation": "validation_step", "Test": "test_step"}
+
+    def _loss_and_pred(self, model, xb, yb, phase, i):
+        """(loss, predictions-or-None) of a batch. Models of this package answer ``training_loss``; a model written for
+        the reference's Trainer (a LightningModule-shaped class: ``training_step`` / ``validation_step`` / ``test_step``
+        returning the loss or ``{"loss": ...}`` and logging through ``self.log``) is driven through those hooks."""
+        if hasattr(model, "training_loss"):
+            return model.training_loss(xb, yb)
+        if not hasattr(model, "log"):          # plain nn.Module with Lightning-style hooks: give it somewhere to log
+            num = lambda v: float(v.detach()) if torch.is_tensor(v) else float(v)
+            model.log = lambda name, value, **kw: self._log({name: num(value)})
+            model.log_dict = lambda d, **kw: self._log({k: num(v) for k, v in d.items()})
+        out = getattr(model, self._STEP_HOOK[phase])((xb, yb), i)
+        return (out["loss"] if isinstance(out, dict) else out), None
+
     def _run_loader(self, loader, phase, train):
         model, dev = self.model, self.device
         C = getattr(self.data, "num_classes", getattr(model, "out_channels", 2))
         C = max(C, 2)
-        cm = torch.zeros(C, C, dtype=torch.int64) if model.is_classifier else None
+        cm = torch.zeros(C, C, dtype=torch.int64) if getattr(model, "is_classifier", False) else None
         total, n, steps = 0.0, 0, 0
         if loader is None:
             return 0.0, cm, 0
@@ -199,13 +214,13 @@ class LightningLearner(NodeLearner):
             if hasattr(self.data, "augment") and train:
                 xb = self.data.augment(xb)                  # on the batch's device (no host round trip)
             if train:
-                loss, pred = model.training_loss(xb, yb)
+                loss, pred = self._loss_and_pred(model, xb, yb, phase, steps)
                 self._optimizer.zero_grad(set_to_none=True)
                 loss.backward()
                 self._optimizer.step()
             else:
                 with torch.no_grad():
-                    loss, pred = model.training_loss(xb, yb)
+                    loss, pred = self._loss_and_pred(model, xb, yb, phase, steps)
             total += float(loss.detach()) * len(xb)
             n += len(xb)
             steps += 1

@@ -23,7 +23,7 @@ import os
 
 import torch
 
-from ..datamodule import FederatedDataModule, synthetic_classification, LOAD_LOCK
+from ..datamodule import ArchiveDataset, FederatedDataModule, sort_dataset, synthetic_classification, LOAD_LOCK  # noqa: F401
 
 
 FEATURE = "system calls frequency_1gram-scaled"
@@ -47,6 +47,34 @@ def process_raw_csvs(files):
     return x[itr], y[itr], x[ite], y[ite], classes
 
 
+class SYSCALL(ArchiveDataset):
+    """The system-call frequency set as a dataset object (reference syscall/syscall.py:21-112): raw tab-separated
+    CSVs -> ``processed/syscall_{train,test}.pt`` = ``[x, y, classes_to_targets, classes]`` (85 / 15 split,
+    ``random_state=42``; classes numbered in sorted name order, see the module docstring)."""
+    FOLDER = "syscall"
+    download_link = "https://files.ifi.uzh.ch/CSG/research/fl/data/syscall.zip"
+
+    def _files(self):
+        pr = os.path.join(self.base, "processed")
+        return [os.path.join(pr, "syscall_train.pt")], [os.path.join(pr, "syscall_test.pt")]
+
+    def process(self):
+        files = sorted(glob.glob(os.path.join(self.base, "raw", "**", "*.csv"), recursive=True))
+        if not files:
+            raise RuntimeError(f"no raw CSV files under {os.path.join(self.base, 'raw')}")
+        tx, ty, ex, ey, classes = process_raw_csvs(files)
+        index = {c: i for i, c in enumerate(classes)}
+        os.makedirs(os.path.join(self.base, "processed"), exist_ok=True)
+        (train_file,), (test_file,) = self._files()
+        torch.save([tx, ty, index, classes], train_file)
+        torch.save([ex, ey, index, classes], test_file)
+
+    def _read(self, train):
+        blob = torch.load(self._files()[0 if train else 1][0], weights_only=True)
+        self.classes_to_targets, self.classes = (blob[2], blob[3]) if len(blob) > 3 else (None, None)
+        return blob[0], blob[1]
+
+
 class SYSCALLDataModule(FederatedDataModule):
     classes = None
     num_classes = 9
@@ -67,7 +95,13 @@ class SYSCALLDataModule(FederatedDataModule):
     @classmethod
     def _load(cls, root):
         pt, csv = os.path.join(root, "syscall.pt"), os.path.join(root, "syscall.csv")
-        if os.path.exists(pt):
+        processed = os.path.join(root, "processed", "syscall_train.pt")      # written by the SYSCALL dataset object
+        if os.path.exists(processed) and os.path.exists(processed.replace("_train", "_test")):
+            tr, te = (torch.load(f, weights_only=True) for f in (processed, processed.replace("_train", "_test")))
+            tx, ty, ex, ey = tr[0], tr[1], te[0], te[1]
+            cls.classes = tr[3] if len(tr) > 3 else None
+            cls.synthetic = False
+        elif os.path.exists(pt):
             tx, ty, ex, ey = torch.load(pt, weights_only=True)
             cls.synthetic = False
         elif glob.glob(os.path.join(root, "raw", "*.csv")):

@@ -11,7 +11,24 @@ import os
 import numpy as np
 import torch
 
-from ..datamodule import FederatedDataModule, synthetic_classification, LOAD_LOCK
+from ..datamodule import ArchiveDataset, FederatedDataModule, synthetic_classification, LOAD_LOCK
+
+
+class WADI(ArchiveDataset):
+    """WADI as a dataset object (reference wadi/wadi.py:20-60): ``X_{train,test}.npy`` / ``y_{train,test}.npy`` under
+    ``<root_dir>/WADI``. The reference's download location is a placeholder ('XXXX', wadi.py:25): there is nothing to
+    fetch, ``download=True`` says where the files have to be placed."""
+    FOLDER = "WADI"
+    download_link = "XXXX"
+    files = ["X_train.npy", "y_train.npy", "X_test.npy", "y_test.npy"]
+
+    def _files(self):
+        f = [os.path.join(self.base, n) for n in self.files]
+        return f[:2], f[2:]
+
+    def _read(self, train):
+        xf, yf = self._files()[0 if train else 1]
+        return torch.from_numpy(np.load(xf)).to(torch.float32), torch.from_numpy(np.load(yf)).to(torch.float32)
 
 
 class WADIDataModule(FederatedDataModule):

@@ -330,3 +330,177 @@ def test_wandb_logger_degrades_to_offline_files(tmp_path):
     lg.finalize_round()
     lg.finalize("success")
     assert any(tmp_path.rglob("*"))
+
+
+@pytest.mark.parametrize("ds,model", [("MNIST", "MLP"), ("FEMNIST", "CNN"), ("SYSCALL", "Autoencoder"), ("CIFAR10", "simplemobilenet")])
+def test_models_carry_the_references_step_and_metric_hooks(ds, model):
+    """training_step / validation_step / test_step, process_metrics, log_metrics_by_epoch and the on_*_epoch_end hooks
+    of the reference's LightningModules (mnist/models/mlp.py:33-222) on every model family; state_dict untouched."""
+    data, m = build_dataset_and_model(ds, model, 0, 20)
+    keys = list(m.state_dict())
+    xb, yb = next(iter(data.train_dataloader()))
+    rows = []
+
+    class Lg:
+        def log_metrics(self, metrics, step=None):
+            rows.append(dict(metrics))
+    m.logger = Lg()
+    loss = m.training_step((xb, yb), 0)
+    assert loss.requires_grad and float(loss.detach()) > 0
+    assert m.logged_metrics["Train/Loss"] == pytest.approx(float(loss.detach()))
+    with torch.no_grad():
+        m.validation_step((xb, yb), 0)
+        m.test_step((xb, yb), 0)
+    if m.is_classifier:
+        assert {"Train/Accuracy", "Train/Precision", "Train/Recall", "Train/F1Score", "Validation/F1Score",
+                "Test/Accuracy"} <= set(m.logged_metrics)
+        assert all(0.0 <= v <= 1.0 for k, v in m.logged_metrics.items() if not k.endswith("Loss"))
+    m.on_train_epoch_end(); m.on_validation_epoch_end(); m.on_test_epoch_end()
+    assert m.epoch_global_number == {"Train": 1, "Validation": 1, "Test": 1}
+    if m.is_classifier:
+        assert "TrainEpoch/Accuracy" in m.logged_metrics and "TestEpoch/F1Score" in m.logged_metrics
+    assert rows and list(m.state_dict()) == keys and str(m.device) == "cpu"
+    with pytest.raises(NotImplementedError):
+        m.process_metrics("Holdout", None, yb)
+
+
+def test_learner_drives_a_lightning_shaped_model_of_the_user():
+    """A model written against the reference's Trainer (training_step / validation_step / test_step that return the
+    loss and call self.log; no hooks of this package) trains and evaluates through LightningLearner."""
+    from p2pfl_amd.config.config import Config, default_participant
+    from p2pfl_amd.learning.pytorch.lightninglearner import LightningLearner
+
+    class Mine(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l = torch.nn.Linear(784, 10)
+
+        def forward(self, x):
+            return self.l(x.reshape(len(x), -1))
+
+        def _step(self, batch, name):
+            x, y = batch
+            loss = torch.nn.functional.cross_entropy(self(x), y)
+            self.log(f"{name}/MyLoss", loss)
+            return loss
+
+        def training_step(self, batch, i):
+            return {"loss": self._step(batch, "Train")}
+
+        def validation_step(self, batch, i):
+            return self._step(batch, "Validation")
+
+        def test_step(self, batch, i):
+            return self._step(batch, "Test")
+
+        def configure_optimizers(self):
+            return torch.optim.SGD(self.parameters(), lr=0.1)
+
+    rows = []
+
+    class Lg:
+        global_step = local_step = 0
+
+        def log_metrics(self, metrics, step=None):
+            rows.append(dict(metrics))
+    p = default_participant()
+    p["device_args"]["accelerator"] = "cpu"
+    data, _ = build_dataset_and_model("MNIST", "MLP", 0, 200)
+    ln = LightningLearner(Mine(), data, config=Config(participant=p), logger=Lg())
+    ln.set_epochs(2)
+    l0, _ = ln.evaluate()
+    ln.fit()
+    l1, _ = ln.evaluate()
+    assert l1 < l0
+    assert any("Train/MyLoss" in r for r in rows) and any("Test/MyLoss" in r for r in rows)
+
+
+def test_dataset_objects_of_the_reference(tmp_path):
+    """FEMNIST / SYSCALL / WADI dataset objects (femnist.py:24-82, syscall.py:21-120, wadi.py:20-60) on small local
+    files: missing files raise unless download=True; FEMNIST is fetched from a file:// archive (checksum-verified,
+    members confined to raw/), SYSCALL is processed from the raw tab-separated CSVs; sort_dataset orders by label."""
+    import hashlib
+    import tarfile
+
+    import numpy as np
+    from p2pfl_amd.learning.pytorch.femnist.femnist import FEMNIST
+    from p2pfl_amd.learning.pytorch.syscall.syscall import FEATURE, SYSCALL, SYSCALLDataModule, sort_dataset
+    from p2pfl_amd.learning.pytorch.wadi.wadi import WADI
+    root = str(tmp_path)
+    with pytest.raises(RuntimeError, match="download=True"):
+        FEMNIST(root_dir=root)
+    # FEMNIST: an archive with the two processed files, served from a file:// URL
+    g = torch.Generator().manual_seed(0)
+    src = tmp_path / "src"
+    src.mkdir()
+    for name, n in (("femnist_train.pt", 12), ("femnist_test.pt", 5)):
+        torch.save((torch.rand(n, 28, 28, generator=g), torch.randint(0, 62, (n,), generator=g)), src / name)
+    arc = tmp_path / "femnist.tar.gz"
+    with tarfile.open(arc, "w:gz") as t:
+        t.add(src / "femnist_train.pt", arcname="femnist_train.pt")
+        t.add(src / "femnist_test.pt", arcname="femnist_test.pt")
+        t.add(src / "femnist_test.pt", arcname="../escaped.pt")                # must not leave raw/
+    md5 = hashlib.md5(arc.read_bytes()).hexdigest()
+
+    class LocalFEMNIST(FEMNIST):
+        download_link, file_md5 = "file://" + str(arc), md5
+    tr = LocalFEMNIST(root_dir=root, download=True)
+    te = LocalFEMNIST(root_dir=root, train=False, transform=lambda x: x.flatten(), target_transform=lambda y: y + 100)
+    assert len(tr) == 12 and len(te) == 5 and tr[0][0].shape == (28, 28) and isinstance(tr[0][1], int)
+    assert te[0][0].shape == (784,) and te[0][1] >= 100
+    assert not (tmp_path / "FEMNIST" / "escaped.pt").exists() and not (tmp_path / "escaped.pt").exists()
+
+    class Tampered(FEMNIST):
+        download_link, file_md5 = "file://" + str(arc), "0" * 32
+    with pytest.raises(RuntimeError, match="checksum"):
+        Tampered(root_dir=str(tmp_path / "other"), download=True)
+    # SYSCALL: raw CSVs -> processed files; the data module then reads what the dataset object wrote
+    raw = tmp_path / "syscall" / "raw"
+    raw.mkdir(parents=True)
+    rows = ["id\t%s\tmaltype" % FEATURE]
+    for i in range(40):
+        rows.append("%d\t%s\t%s" % (i, [round(0.01 * ((i * 7 + j) % 13), 3) for j in range(17)],
+                                     ["normal", "normalv2", "bashlite", "thetick"][i % 4]))
+    (raw / "a.csv").write_text("\n".join(rows) + "\n")
+
+    class LocalSYSCALL(SYSCALL):
+        def dataset_download(self):          # the raw files are already in place
+            os.makedirs(os.path.join(self.base, "processed"), exist_ok=True)
+    s_tr, s_te = LocalSYSCALL(root_dir=root, download=True), LocalSYSCALL(root_dir=root, train=False)
+    assert len(s_tr) == 34 and len(s_te) == 6 and s_tr.classes == ["bashlite", "normal", "thetick"]
+    assert s_tr[0][0].shape == (17,) and s_tr.classes_to_targets["normal"] == 1
+    sort_dataset(s_tr)
+    assert bool((s_tr.targets[1:] >= s_tr.targets[:-1]).all())
+    SYSCALLDataModule.train_set = None
+    try:
+        dm = SYSCALLDataModule(0, 2, root_dir=str(tmp_path / "syscall"))
+        assert not SYSCALLDataModule.synthetic and dm.num_samples() == (17, 3)
+    finally:
+        SYSCALLDataModule.train_set = None
+    # WADI: numpy files; no download location exists (the reference's is a placeholder)
+    with pytest.raises(RuntimeError, match="no download location"):
+        WADI(root_dir=root, download=True)
+    (tmp_path / "WADI").mkdir()
+    for name, shape in (("X_train.npy", (9, 123)), ("y_train.npy", (9,)), ("X_test.npy", (4, 123)), ("y_test.npy", (4,))):
+        np.save(tmp_path / "WADI" / name, np.ones(shape))
+    w = WADI(root_dir=root, train=False)
+    assert len(w) == 4 and w[0][0].dtype == torch.float32 and w[0][1] == 1
+
+
+def test_cifar10_normalization_and_whole_dataset_access():
+    from p2pfl_amd.learning.pytorch.cifar10.cifar10 import CIFAR10DataModule
+    assert CIFAR10DataModule.set_normalization("imagenet")["mean"] == (0.485, 0.456, 0.406)
+    with pytest.raises(NotImplementedError):
+        CIFAR10DataModule.set_normalization("other")
+    with pytest.raises(NotImplementedError):
+        CIFAR10DataModule(0, 50, loading="custom")
+    a = CIFAR10DataModule(0, 50)
+    b = CIFAR10DataModule(0, 50, normalization="imagenet")
+    assert a.mean == (0.4914, 0.4822, 0.4465) and b.std == (0.229, 0.224, 0.225)
+    ra = a.train_x.reshape(-1, 3, 32, 32) * torch.tensor(a.std).view(1, 3, 1, 1) + torch.tensor(a.mean).view(1, 3, 1, 1)
+    rb = b.train_x.reshape(-1, 3, 32, 32) * torch.tensor(b.std).view(1, 3, 1, 1) + torch.tensor(b.mean).view(1, 3, 1, 1)
+    assert torch.allclose(ra, rb, atol=1e-5)                      # the same pixels under both statistics
+    whole = a.get_dataset(train=True)
+    assert len(whole) == 50 * len(a.train_x) and whole[0][0].shape == (3, 32, 32)
+    flipped = a.get_dataset(train=False, transform=lambda x: x.flip(-1))
+    assert torch.equal(flipped[3][0], a.get_dataset(train=False)[3][0].flip(-1))

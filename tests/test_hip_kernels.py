@@ -266,8 +266,7 @@ def test_conv1_wgrad(ks, B, Fm, K, prec):
 @pytest.mark.parametrize("ks,B,K", [(5, 32, 2), (3, 32, 2), (5, 9, 3), (5, 32, 11), (3, 7, 9)])
 def test_conv2_fwd(ks, B, K, prec, cores):
     h = hip()
-    if cores and prec != "fp32-mfma":
-        pytest.skip("co-resident (small-footprint) variants exist for the fp32 MFMA kernels only")
+    assert not cores or prec == "fp32-mfma"      # (other combinations are dropped at collection: tests/conftest.py)
     Cin, Cout = 32, 64
     a1 = torch.randn(K, B, Cin, 196, device=DEV).relu()
     w = slab_view(K, (Cout, Cin * ks * ks)) * 0.05
@@ -288,8 +287,7 @@ def test_conv2_fwd(ks, B, K, prec, cores):
                                     (5, 32, 100)])
 def test_conv2_wgrad_dgrad(ks, B, K, prec, cores):
     h = hip()
-    if cores and prec != "fp32-mfma":
-        pytest.skip("co-resident (small-footprint) variants exist for the fp32 MFMA kernels only")
+    assert not cores or prec == "fp32-mfma"      # (other combinations are dropped at collection: tests/conftest.py)
     Cin, Cout = 32, 64
     a1 = torch.randn(K, B, Cin, 196, device=DEV).relu()
     w = slab_view(K, (Cout, Cin * ks * ks)) * 0.05

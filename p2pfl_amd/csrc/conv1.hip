@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1WgradArgs a) {
 // the layer's optimizer step (the gradient value is final here, so it never has to reach memory).
 // A block owns a quarter of one 32 x 32 tile (jn) of one client, thread = (accumulator register e, lane) of the MFMA
 // tile layout: 4 * njn blocks per client - one 1024-thread block per client left 10-client shards with 10 blocks, each
-// walking up to 128 partials one dependent load after the other (87 us per step on the critical chain). The loads of 8
+// walking up to 128 partials one dependent load after the other (87 us per step on the critical chain). The loads of up to 32
 // partials are in flight together; the ADDS stay in index order, so the sum is bit-equal to the one-by-one loop.
 struct Conv1FinishArgs {
     const float* part; int nparts, njn, tap8;
@@ -355,6 +355,14 @@ __global__ __launch_bounds__(256) void conv1_wgrad_finish_kernel(Conv1FinishArgs
     const size_t ks = (size_t)a.njn * 1024;
     float s = 0.f;
     int k = 0;
+    // (32 loads in flight: a 10-client shard has 128 partials per sum - 4 memory round trips instead of 16)
+    for (; k + 32 <= a.nparts; k += 32) {
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = p[(size_t)(k + u) * ks];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) s += v[u];
+    }
     for (; k + 8 <= a.nparts; k += 8) {
         float v[8];
 #pragma unroll

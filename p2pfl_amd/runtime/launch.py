@@ -329,6 +329,10 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
         with open(os.path.join(log_root, "summary.json"), "w") as f:
             json.dump(summary, f, indent=2)
     if world > 1:
+        try:                      # leave together: a rank that tears its communicator down while a peer still
+            dist.barrier()        # finishes a collective makes that peer abort
+        except Exception as e:    # noqa: BLE001 - a peer that already died must not keep this rank from exiting
+            logging.warning("final barrier failed: %s", e)
         dist.destroy_process_group()
     return summary
 

@@ -21,6 +21,7 @@ from typing import Callable, Dict, Optional
 import torch.distributed as dist
 
 HEADER = struct.Struct("!IBi")
+MAX_PAYLOAD = 1 << 20      # control messages are a few hundred bytes; anything larger is a broken stream
 
 # frame kinds
 BUS = 1          # a wire-format control message of node `sender` (BEAT / ROLE / MODELS_READY / ...), payload = the message
@@ -46,16 +47,28 @@ class RankBridge:
         srv.listen(max(world, 8))
         srv.settimeout(timeout)
         addrs = [None] * world
-        dist.all_gather_object(addrs, (addr, srv.getsockname()[1]), group=group)
+        dist.all_gather_object(addrs, (addr, srv.getsockname()[1], os.urandom(16)), group=group)
+        # the job's token (rank 0's draw, known to the ranks only - it travelled over the process group): whoever dials
+        # a bridge port has to present it, so another process of the machine cannot pose as a rank
+        token = addrs[0][2]
         # lower ranks are dialled, higher ranks dial in (the listen backlog holds them until the accepts below)
         for r in range(rank):
-            s = socket.create_connection(tuple(addrs[r]), timeout=timeout)
-            s.sendall(struct.pack("!I", rank))
+            s = socket.create_connection(tuple(addrs[r][:2]), timeout=timeout)
+            s.sendall(struct.pack("!I", rank) + token)
             self._add(r, s)
-        for _ in range(world - 1 - rank):
+        while len(self._peers) < world - 1:
             s, _peer = srv.accept()
             s.settimeout(timeout)
-            r = struct.unpack("!I", self._recv_exact(s, 4))[0]
+            try:
+                hello = self._recv_exact(s, 4 + len(token))
+            except (ConnectionError, OSError):
+                s.close()
+                continue
+            r = struct.unpack("!I", hello[:4])[0]
+            if hello[4:] != token or not rank < r < world or r in self._peers:
+                logging.warning("[BRIDGE] rank %d: refused a connection that did not present the job's token", rank)
+                s.close()
+                continue
             self._add(r, s)
         srv.close()
         self._threads = [threading.Thread(target=self._reader, args=(r, s), name=f"rank-bridge-{rank}<-{r}", daemon=True)
@@ -83,7 +96,10 @@ class RankBridge:
         try:
             while not self._closed.is_set():
                 n, kind, sender = HEADER.unpack(self._recv_exact(s, HEADER.size))
+                if n > MAX_PAYLOAD:
+                    raise ConnectionError(f"rank bridge: frame of {n} bytes")
                 payload = self._recv_exact(s, n) if n else b""
+
                 try:
                     self.on_frame(r, kind, sender, payload)
                 except Exception as e:      # noqa: BLE001 - a faulty handler must not take the link down

@@ -212,3 +212,53 @@ def test_batched_launcher_control_plane_on_two_ranks(tmp_path):
         assert "round 1 role aggregator alive True" in (logs / f"participant_{i}.log").read_text()
     assert f"TCP gateway of virtual node 3 listening on 127.0.0.1:{gw_port}" in (logs / "participant_3.log").read_text()
     assert "TCP gateway" not in (logs / "participant_0.log").read_text()
+
+
+def test_rank_bridge_refuses_connections_without_the_job_token(monkeypatch):
+    """The mesh is for the ranks of ONE job: a process of the machine that dials a bridge port without the token the
+    ranks exchanged over their process group is turned away, and the real rank still gets in."""
+    import struct
+    import threading
+
+    from p2pfl_amd.runtime import bridge as B
+    shared, cv = {}, threading.Condition()
+
+    def fake_gather(out, obj, group=None):
+        with cv:
+            shared[group] = obj                      # group = the rank, in this test
+            cv.notify_all()
+            cv.wait_for(lambda: len(shared) == 2, timeout=10)
+        out[0], out[1] = shared[0], shared[1]
+        if group == 1:                               # before rank 1 dials: an intruder takes the first accept slot
+            s = socket.create_connection(tuple(shared[0][:2]), timeout=5)
+            s.sendall(struct.pack("!I", 1) + b"x" * 16)
+            intruders.append(s)
+    monkeypatch.setattr(B.dist, "all_gather_object", fake_gather)
+    intruders, got, bridges = [], [], {}
+
+    def make(rank):
+        bridges[rank] = B.RankBridge(rank, 2, rank, lambda src, kind, sender, payload: got.append((rank, src, kind, sender, payload)),
+                                     timeout=10)
+    ts = [threading.Thread(target=make, args=(r,)) for r in (0, 1)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(20)
+    assert sorted(bridges) == [0, 1]
+    try:
+        bridges[1].send_all(B.BUS, 5, b"BEAT 127.0.0.1:45005")
+        deadline = time.time() + 5
+        while not got and time.time() < deadline:
+            time.sleep(0.01)
+        assert got == [(0, 1, B.BUS, 5, b"BEAT 127.0.0.1:45005")]
+        intruders[0].settimeout(2)
+        assert intruders[0].recv(1) == b""           # closed by rank 0
+        # an oversized frame ends the link instead of allocating what the header claims
+        bridges[1]._peers[0].sendall(B.HEADER.pack(B.MAX_PAYLOAD + 1, B.BUS, 0))
+        bridges[0]._threads[0].join(5)
+        assert not bridges[0]._threads[0].is_alive()
+    finally:
+        for b in bridges.values():
+            b.close()
+        for s in intruders:
+            s.close()

@@ -63,6 +63,42 @@ __global__ __launch_bounds__(64) void softmax_ce_kernel(CeArgs a) {
     }
 }
 
+// One logit per sample (C == 1): sigmoid + binary cross-entropy, the loss of the reference's WADI model
+// (fedstellar/learning/pytorch/wadi/models/mlp.py: torch.sigmoid in forward, BCELoss) - the two-class softmax over the
+// logits (0, z). loss = softplus(z) - y z computed in its stable form, d loss / dz = (sigmoid(z) - y) / n_valid, the
+// prediction is z > 0 (p > 0.5); the confusion matrix is 2 x 2.
+__global__ __launch_bounds__(64) void sigmoid_bce_kernel(CeArgs a) {
+    const int c = blockIdx.x;
+    const int nv = a.n_valid ? min(a.n_valid[c * a.nv_cs], a.B) : a.B;
+    const float inv = nv > 0 ? 1.f / (float)nv : 0.f;
+    float lsum = 0.f; int lcorrect = 0;
+    for (int b = threadIdx.x; b < a.B; b += 64) {
+        float* dz = a.dlogits ? a.dlogits + c * a.d_cs + b : nullptr;
+        if (b >= nv) {
+            if (dz) *dz = 0.f;
+            continue;
+        }
+        const int sample = a.sidx ? a.sidx[c * a.s_cs + b] : b;
+        const int y = a.labels[c * a.y_cs + sample] != 0;
+        const float z = a.logits[c * a.l_cs + b];
+        const float e = expf(-fabsf(z));                       // in (0, 1]: no overflow either way
+        // (BCELoss clamps its logarithms at -100, i.e. the loss of one sample at 100)
+        lsum += fminf(fmaxf(z, 0.f) - (y ? z : 0.f) + log1pf(e), 100.f);
+        const float p = z >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        const int pred = p > 0.5f;
+        lcorrect += (pred == y);
+        if (dz) *dz = (p - (float)y) * inv;
+        if (a.confusion) atomicAdd(a.confusion + ((size_t)c * 2 + y) * 2 + pred, 1);
+    }
+    lsum = wave_reduce_sum(lsum);
+    float fc = wave_reduce_sum((float)lcorrect);
+    if (threadIdx.x == 0) {
+        a.loss_sum[c] += lsum;
+        a.correct[c] += (int)(fc + 0.5f);
+        a.count[c] += nv;
+    }
+}
+
 // Many classes (FEMNIST: 62): a lane per row means three passes of stride-C loads (29 us for 50 clients). Here a
 // block of 16 waves serves a client, a wave takes rows w, w + 16, ..., and a lane owns ONE class (C <= 64): a row is
 // one coalesced load, the reductions are wave shuffles, the gradient one coalesced store. (For the 10-class models
@@ -130,7 +166,8 @@ P2PFL_API int p2pfl_softmax_ce(const float* logits, long l_cs, const int* labels
     if (K <= 0 || B <= 0 || C <= 0) return -1;
     CeArgs a{logits, l_cs, labels, y_cs, sidx, s_cs, dlogits, d_cs, loss_sum, correct, count,
              confusion, n_valid, nv_cs, B, C};
-    if (C > 16 && C <= 64) hipLaunchKernelGGL(softmax_ce_wide_kernel, dim3(K), dim3(64 * CE_WAVES), 0, stream, a);
+    if (C == 1) hipLaunchKernelGGL(sigmoid_bce_kernel, dim3(K), dim3(64), 0, stream, a);     // confusion: [K][2][2]
+    else if (C > 16 && C <= 64) hipLaunchKernelGGL(softmax_ce_wide_kernel, dim3(K), dim3(64 * CE_WAVES), 0, stream, a);
     else hipLaunchKernelGGL(softmax_ce_kernel, dim3(K), dim3(64), 0, stream, a);
     P2PFL_RETURN_LAST_ERROR();
 }

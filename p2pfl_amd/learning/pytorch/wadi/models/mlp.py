@@ -5,10 +5,13 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from .....models import specs
 from .....models.torch_models import FederatedModule
 
 
 class WADIModelMLP(FederatedModule):
+    spec_factory = staticmethod(specs.wadi_mlp)     # runs on the client-batched HIP kernels (loss: csrc/loss.hip, C = 1)
+
     def __init__(self, in_channels=123, out_channels=1, learning_rate=1e-3, metrics=None, confusion_matrix=None,
                  seed=None):
         super().__init__(in_channels, out_channels, learning_rate, metrics, confusion_matrix, seed)

@@ -9,6 +9,8 @@ Reference architectures:
 * MNIST CNN      – fedstellar/learning/pytorch/mnist/models/cnn.py:134-164 (its ``forward`` returns
   the input instead of the logits, cnn.py:159; this build returns logits)
 * FEMNIST CNN    – fedstellar/learning/pytorch/femnist/models/cnn.py:136-157
+* WADI MLP       – fedstellar/learning/pytorch/wadi/models/mlp.py (nine linear layers, ReLU between, ONE logit through a
+  sigmoid + BCELoss = the two-class problem the loss kernel solves for C = 1)
 """
 from __future__ import annotations
 
@@ -141,7 +143,25 @@ def femnist_cnn(num_classes: int = 62, lr: float = 1e-3) -> ModelSpec:
     )
 
 
+WADI_DIMS = (123, 1024, 512, 256, 128, 64, 32, 16, 8)
+
+
+def wadi_mlp(num_classes: int = 1, lr: float = 1e-3) -> ModelSpec:
+    """``num_classes`` = outputs of the last layer as the model's constructor names them (``out_channels`` = 1: one
+    logit); the labels are binary, so the engine's counters and confusion matrix have TWO classes."""
+    if num_classes != 1:
+        raise ValueError("the WADI MLP has one output (sigmoid + BCE)")
+    dims = WADI_DIMS + (1,)
+    params, layers = [], []
+    for i in range(9):
+        params += [ParamSpec(f"l{i + 1}.weight", (dims[i + 1], dims[i])), ParamSpec(f"l{i + 1}.bias", (dims[i + 1],))]
+        layers.append(LayerSpec("linear", f"l{i + 1}.weight", f"l{i + 1}.bias", dims[i], dims[i + 1], relu=i < 8))
+    return ModelSpec(name="wadi-mlp", params=tuple(params), layers=tuple(layers), optim=OptimSpec("adam", lr),
+                     num_classes=2, input_shape=(1, 1, 123))
+
+
 SPECS = {
+    "wadi-mlp": wadi_mlp,
     "mnist-mlp": mnist_mlp,
     "mnist-cnn": mnist_cnn,
     "femnist-cnn": femnist_cnn,

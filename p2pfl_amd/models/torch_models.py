@@ -172,8 +172,10 @@ class FederatedModule(nn.Module):
 # module can be imported first.
 _LAZY = {"MNISTModelMLP": "p2pfl_amd.learning.pytorch.mnist.models.mlp",
          "MNISTModelCNN": "p2pfl_amd.learning.pytorch.mnist.models.cnn",
-         "FEMNISTModelCNN": "p2pfl_amd.learning.pytorch.femnist.models.cnn"}
-_BY_SPEC = {"mnist-mlp": "MNISTModelMLP", "mnist-cnn": "MNISTModelCNN", "femnist-cnn": "FEMNISTModelCNN"}
+         "FEMNISTModelCNN": "p2pfl_amd.learning.pytorch.femnist.models.cnn",
+         "WADIModelMLP": "p2pfl_amd.learning.pytorch.wadi.models.mlp"}
+_BY_SPEC = {"mnist-mlp": "MNISTModelMLP", "mnist-cnn": "MNISTModelCNN", "femnist-cnn": "FEMNISTModelCNN",
+            "wadi-mlp": "WADIModelMLP"}
 
 
 def __getattr__(name):
@@ -185,4 +187,6 @@ def __getattr__(name):
 
 def module_for_spec(spec: specs.ModelSpec, seed=None) -> FederatedModule:
     cls = __getattr__(_BY_SPEC[spec.name])
+    if spec.name == "wadi-mlp":                     # one output, two classes (see specs.wadi_mlp)
+        return cls(learning_rate=spec.optim.lr, seed=seed)
     return cls(out_channels=spec.num_classes, learning_rate=spec.optim.lr, seed=seed)

@@ -334,17 +334,14 @@ class EagerEngine(ShardEngine):
         for s in range(0, n, self.B):
             idx = order[s:s + self.B] if order is not None else torch.arange(s, min(s + self.B, n), device=self.device)
             xb, yb = x[idx], y[idx].long()
-            if train:
-                out = m(xb)
-                loss = m.criterion(out, yb)
+            if train:                                        # (training_loss: criterion + predictions of the family -
+                loss, pred = m.training_loss(xb, yb)         #  arg-max of the logits, p > 0.5 for the one-logit WADI MLP)
                 optim.zero_grad(set_to_none=True)
                 loss.backward()
                 optim.step()
             else:
                 with torch.no_grad():
-                    out = m(xb)
-                    loss = m.criterion(out, yb)
-            pred = out.detach().argmax(dim=1)
+                    loss, pred = m.training_loss(xb, yb)
             st.loss_sum[k] += loss.detach() * len(idx)
             st.correct[k] += (pred == yb).sum().to(torch.int32)
             st.count[k] += len(idx)

@@ -35,7 +35,11 @@ from ..node_start import build_dataset_and_model, build_model
 from ..parallel.planner import locality_placement, placement_order
 from .federation import BatchedFederation
 
-_SPEC_OF = {("MNIST", "MLP"): "mnist-mlp", ("MNIST", "CNN"): "mnist-cnn", ("FEMNIST", "CNN"): "femnist-cnn"}
+_SPEC_OF = {("MNIST", "MLP"): "mnist-mlp", ("MNIST", "CNN"): "mnist-cnn", ("FEMNIST", "CNN"): "femnist-cnn",
+            ("WADI", "MLP"): "wadi-mlp"}
+# on the CPU these families stay on the client-batched stock-op engine (one vmap step for all nodes) instead of the
+# per-node loop that is the CPU side of a kernel-level spec
+_GPU_ONLY_SPECS = {("WADI", "MLP")}
 
 
 def load_participants(config_dir: str) -> List[dict]:
@@ -134,7 +138,7 @@ def run_scenario(config_dir: str, device: str = "auto", encrypt: bool = False, s
     p0 = parts[pos[0]]
     key = (p0["data_args"]["dataset"], p0["model_args"]["model"])
     root_dir = p0["data_args"].get("root_dir")
-    if key in _SPEC_OF:
+    if key in _SPEC_OF and (str(dev).startswith("cuda") or key not in _GPU_ONLY_SPECS):
         spec = get_spec(_SPEC_OF[key])               # client-batched HIP kernels
     else:
         # every other family of the reference's factory: its nn.Module on stock PyTorch-ROCm ops, state in the

@@ -133,6 +133,55 @@ def test_inactive_clients_keep_persistent_optimizer_state():
     assert not torch.equal(h.m[0], m[0]) and not torch.equal(h.params[2], p[2])
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_wadi_mlp_trains_on_the_kernels_like_the_eager_engine(precision):
+    """The fourth family with a kernel-level spec: nine linear layers (123 -> 1024 -> ... -> 8 -> 1, In = 123 is not a
+    multiple of four: element loads), ReLU between, ONE logit through sigmoid + BCE, Adam - against the nn.Module
+    (reference wadi/models/mlp.py) under autograd: first-step gradients, then two epochs of training."""
+    from p2pfl_amd.models.specs import get_spec
+    from p2pfl_amd.runtime.engine import EagerEngine, HipEngine
+    spec = get_spec("wadi-mlp")
+    K, n, B = 3, 96, 32
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(K, n, 123, generator=g)
+    w = torch.randn(123, generator=g)
+    y = ((x @ w) > 0).long()
+    data = [t.cuda() for t in (x, y, x[:, :32], y[:, :32], x[:, :64], y[:, :64])]
+    h = HipEngine(spec, K, "cuda", seed=11, use_graph=False, fuse_optimizer=False, precision=precision)
+    e = EagerEngine(spec, K, "cuda", seed=11)
+    h.init_params(identical=False)
+    e.params.copy_(h.params)
+    h.set_data(*data); e.set_data(*data)
+    assert h.stats["Train"].confusion.shape == (K, 2, 2)
+    sidx = torch.stack([torch.randperm(n, device="cuda")[:B] for _ in range(K)]).int()
+    h.stats["Train"].zero_()
+    h._forward(h.train_x, sidx, h.train_y, h._nv(B), "Train", train=True)
+    h._backward(h.train_x, sidx)
+    torch.cuda.synchronize()
+    f32 = precision == "fp32"
+    for k in range(K):
+        m = e.modules[k]
+        m.zero_grad()
+        loss, _ = m.training_loss(e.train_x[k][sidx[k].long()], e.train_y[k][sidx[k].long()].long())
+        loss.backward()
+        assert abs(h.stats["Train"].loss_sum[k].item() / B - loss.item()) < (1e-5 if f32 else 2e-2)
+        for pname, p_ in m.named_parameters():
+            gk = h.grad_view(pname)[k]
+            err = (gk - p_.grad).norm() / p_.grad.norm().clamp(min=1e-12)
+            assert err < (1e-4 if f32 else 0.25), f"{pname}: rel err {err:.3e}"      # (bf16 rounding through 9 layers)
+    # whole fits (fused / folded optimizer paths, graph replay) against the eager engine
+    h2 = HipEngine(spec, K, "cuda", seed=11, precision=precision)
+    h2.params.copy_(e.params)
+    h2.set_data(*data)
+    o_h, o_e = h2.fit(2), e.fit(2)
+    t_h, t_e = h2.evaluate(), e.evaluate()
+    tol = 5e-3 if f32 else 5e-2
+    assert torch.allclose(o_h["Train"]["loss"].cpu(), o_e["Train"]["loss"].cpu(), atol=tol)
+    assert torch.allclose(t_h["loss"].cpu(), t_e["loss"].cpu(), atol=tol)
+    assert (t_h["accuracy"].cpu() - t_e["accuracy"].cpu()).abs().max() <= (0.02 if f32 else 0.08)
+    assert bool(torch.isfinite(h2.params).all())
+
+
 def test_prepare_leaves_no_trace():
     """prepare() captures the graphs with a dry-run round; training afterwards == training without it."""
     from p2pfl_amd.datasets.synthetic import synthetic_shards

@@ -446,6 +446,37 @@ def test_softmax_ce(C, B, nv):
         assert (cm[k] == ref_cm).all()
 
 
+@pytest.mark.parametrize("B,nv", [(32, 32), (32, 19), (100, 64)])
+def test_sigmoid_bce_for_one_logit_models(B, nv):
+    """C = 1: sigmoid + binary cross-entropy (the WADI MLP's loss, wadi/models/mlp.py: torch.sigmoid + BCELoss) with a
+    2 x 2 confusion matrix; extreme logits stay finite (BCELoss clamps a sample's loss at 100)."""
+    h = hip()
+    K, n = 3, 150
+    logits = torch.randn(K, B, 1, device=DEV) * 4
+    logits[0, 0, 0], logits[0, 1, 0] = 300.0, -300.0
+    labels = torch.randint(0, 2, (K, n), device=DEV).int()
+    sidx = torch.stack([torch.randperm(n, device=DEV)[:B] for _ in range(K)]).int()
+    labels[0, sidx[0, 0].long()], labels[0, sidx[0, 1].long()] = 0, 1          # both as wrong as a sample can be
+    dl = torch.empty_like(logits)
+    loss = torch.zeros(K, device=DEV)
+    corr = torch.zeros(K, dtype=torch.int32, device=DEV)
+    cnt = torch.zeros(K, dtype=torch.int32, device=DEV)
+    cm = torch.zeros(K, 2, 2, dtype=torch.int32, device=DEV)
+    h.softmax_ce(logits, labels, sidx, dl, loss, corr, cnt, cm, torch.full((K,), nv, dtype=torch.int32, device=DEV))
+    for k in range(K):
+        y = labels[k][sidx[k].long()].float()[:nv]
+        z = logits[k, :nv, 0].clone().requires_grad_(True)
+        ref = F.binary_cross_entropy(torch.sigmoid(z), y, reduction="sum")        # the reference's own formulation
+        (F.binary_cross_entropy_with_logits(z, y, reduction="sum") / nv).backward()
+        assert torch.isfinite(loss[k]) and torch.allclose(loss[k], ref.detach(), rtol=1e-4, atol=1e-3)
+        assert torch.allclose(dl[k, :nv, 0], z.grad, atol=1e-6, rtol=1e-4) and (dl[k, nv:] == 0).all()
+        pred = (logits[k, :nv, 0] > 0).long()
+        assert corr[k].item() == (pred == y.long()).sum().item() and cnt[k].item() == nv
+        ref_cm = torch.zeros(4, dtype=torch.int32, device=DEV).index_add_(
+            0, y.long() * 2 + pred, torch.ones(nv, dtype=torch.int32, device=DEV)).view(2, 2)
+        assert (cm[k] == ref_cm).all()
+
+
 def test_adam_two_ranges_in_one_launch_match_torch_and_leave_the_gap_alone():
     h = hip()
     K, P = 5, 4096

@@ -504,3 +504,31 @@ def test_cifar10_normalization_and_whole_dataset_access():
     assert len(whole) == 50 * len(a.train_x) and whole[0][0].shape == (3, 32, 32)
     flipped = a.get_dataset(train=False, transform=lambda x: x.flip(-1))
     assert torch.equal(flipped[3][0], a.get_dataset(train=False)[3][0].flip(-1))
+
+
+def test_wadi_mlp_has_a_kernel_level_spec():
+    """The WADI MLP joins MNIST MLP / CNN and FEMNIST CNN on the client-batched kernels: its spec lists the module's
+    state_dict in order, one output = two classes, and the CPU side of the spec (EagerEngine) trains it with the
+    module's own sigmoid + BCE loss."""
+    from p2pfl_amd.learning.pytorch.wadi.models.mlp import WADIModelMLP
+    from p2pfl_amd.models.specs import get_spec
+    from p2pfl_amd.models.torch_models import module_for_spec
+    from p2pfl_amd.runtime.engine import EagerEngine
+    from p2pfl_amd.runtime.launch import _GPU_ONLY_SPECS, _SPEC_OF
+    spec, m = get_spec("wadi-mlp"), WADIModelMLP()
+    sd = m.state_dict()
+    assert [p.name for p in spec.params] == list(sd) and all(tuple(sd[p.name].shape) == p.shape for p in spec.params)
+    assert m.spec.name == "wadi-mlp" and spec.num_classes == 2 and spec.layers[-1].out_features == 1
+    assert [l.relu for l in spec.layers] == [True] * 8 + [False]
+    assert isinstance(module_for_spec(spec), WADIModelMLP)
+    assert _SPEC_OF[("WADI", "MLP")] == "wadi-mlp" and ("WADI", "MLP") in _GPU_ONLY_SPECS
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 64, 123, generator=g)
+    y = (x[:, :, 0] > 0).long()
+    eng = EagerEngine(spec, 2, "cpu", batch_size=16, seed=1)
+    eng.init_params()
+    eng.set_data(x, y, x[:, :16], y[:, :16], x[:, :32], y[:, :32])
+    l0 = eng.evaluate()["loss"].clone()
+    out = eng.fit(3)
+    assert out["Train"]["confusion"].shape == (2, 2, 2) and int(out["Train"]["count"][0]) == 64
+    assert bool((eng.evaluate()["loss"] < l0).all())

@@ -44,6 +44,23 @@ for ds, model, K, n in CASES:
             print(f"  {ds}-{model} {mode} failed: {type(exc).__name__}: {str(exc)[:200]}")
         del eng
         torch.cuda.empty_cache()
+    hip_ms = ""
+    kspec = getattr(build_model(ds, model), "spec", None)
+    if kspec is not None:                     # a family that ALSO has a kernel-level spec: the same round on the HIP engine
+        from p2pfl_amd.runtime.engine import HipEngine
+        eng = HipEngine(kspec, K, dev, seed=1, batch_size=32)
+        eng.set_data(*data)
+        eng.init_params()
+        for _ in range(3):
+            eng.evaluate(); eng.fit(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.evaluate(); out = eng.fit(1)
+        float(out["Train"]["loss"].mean())
+        torch.cuda.synchronize()
+        hip_ms = f"   HIP kernels {(time.perf_counter() - t0)*1e3:8.1f} ms"
+        del eng
+        torch.cuda.empty_cache()
     print(f"{ds}-{model:16s} K={K:3d} n={n:4d}: per-node loop {times['loop']*1e3:8.1f} ms   client-batched {times['vmap']*1e3:8.1f} ms "
-          f"(x{times['loop'] / times['vmap']:.1f})   + hipGraph replay {times['vmap+graph']*1e3:8.1f} ms (x{times['loop'] / times['vmap+graph']:.1f})",
+          f"(x{times['loop'] / times['vmap']:.1f})   + hipGraph replay {times['vmap+graph']*1e3:8.1f} ms (x{times['loop'] / times['vmap+graph']:.1f}){hip_ms}",
           flush=True)

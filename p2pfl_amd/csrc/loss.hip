@@ -99,6 +99,48 @@ __global__ __launch_bounds__(64) void sigmoid_bce_kernel(CeArgs a) {
     }
 }
 
+// Reconstruction loss of the auto-encoders (reference syscall/models/autoencoder.py: MSELoss between the decoder
+// output and the INPUT batch): loss = mean over the n_valid x D elements of (out - x)^2, d loss / d out =
+// 2 (out - x) / (n_valid D); x rows are gathered from the client's data with the batch's sample indices. One block
+// per client; the block's sum is formed in a fixed order (bitwise reproducible).
+struct MseArgs {
+    const float* out; long o_cs;        // [K][B][D]
+    const float* x;   long x_cs;        // [K][n][D]
+    const int* sidx;  long s_cs;        // [K][B] (or null: rows 0 .. B-1)
+    float* dout;      long d_cs;        // [K][B][D] (null on the evaluation path)
+    float* loss_sum; int* count;
+    const int* n_valid; long nv_cs;
+    int B, D;
+};
+
+__global__ __launch_bounds__(256) void mse_input_kernel(MseArgs a) {
+    __shared__ float s_part[4];
+    const int c = blockIdx.x;
+    const int nv = a.n_valid ? min(a.n_valid[c * a.nv_cs], a.B) : a.B;
+    const float inv = nv > 0 ? 1.f / ((float)nv * (float)a.D) : 0.f;
+    float l = 0.f;
+    for (int i = threadIdx.x; i < a.B * a.D; i += 256) {
+        const int b = i / a.D, j = i - b * a.D;
+        float* dz = a.dout ? a.dout + c * a.d_cs + i : nullptr;
+        if (b >= nv) {
+            if (dz) *dz = 0.f;
+            continue;
+        }
+        const int row = a.sidx ? a.sidx[c * a.s_cs + b] : b;
+        const float d = a.out[c * a.o_cs + i] - a.x[c * a.x_cs + (size_t)row * a.D + j];
+        l += d * d;
+        if (dz) *dz = 2.f * d * inv;
+    }
+    l = wave_reduce_sum(l);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = l;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float sum = ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3];
+        a.loss_sum[c] += sum * inv * (float)nv;        // the engines accumulate (mean loss of the batch) x (its samples)
+        a.count[c] += nv;
+    }
+}
+
 // Many classes (FEMNIST: 62): a lane per row means three passes of stride-C loads (29 us for 50 clients). Here a
 // block of 16 waves serves a client, a wave takes rows w, w + 16, ..., and a lane owns ONE class (C <= 64): a row is
 // one coalesced load, the reductions are wave shuffles, the gradient one coalesced store. (For the 10-class models
@@ -169,6 +211,15 @@ P2PFL_API int p2pfl_softmax_ce(const float* logits, long l_cs, const int* labels
     if (C == 1) hipLaunchKernelGGL(sigmoid_bce_kernel, dim3(K), dim3(64), 0, stream, a);     // confusion: [K][2][2]
     else if (C > 16 && C <= 64) hipLaunchKernelGGL(softmax_ce_wide_kernel, dim3(K), dim3(64 * CE_WAVES), 0, stream, a);
     else hipLaunchKernelGGL(softmax_ce_kernel, dim3(K), dim3(64), 0, stream, a);
+    P2PFL_RETURN_LAST_ERROR();
+}
+
+P2PFL_API int p2pfl_mse_input(const float* out, long o_cs, const float* x, long x_cs, const int* sidx, long s_cs,
+                              float* dout, long d_cs, float* loss_sum, int* count, const int* n_valid, long nv_cs,
+                              int K, int B, int D, hipStream_t stream) {
+    if (K <= 0 || B <= 0 || D <= 0) return -1;
+    MseArgs a{out, o_cs, x, x_cs, sidx, s_cs, dout, d_cs, loss_sum, count, n_valid, nv_cs, B, D};
+    hipLaunchKernelGGL(mse_input_kernel, dim3(K), dim3(256), 0, stream, a);
     P2PFL_RETURN_LAST_ERROR();
 }
 

@@ -252,16 +252,18 @@ class LightningLearner(NodeLearner):
                 eng.synchronize()
                 self._local_step = eng.steps_per_epoch() * self.epochs
                 per_step = eng.step_losses()
+                clsf = getattr(self.model, "is_classifier", True)
                 if per_step is not None:            # the per-step series, every 20 steps (lightninglearner.py:188;
                     per_cm = eng.step_metrics()     # mnist/models/mlp.py:33-106: loss + macro metrics of the batch)
                     for t in range(19, per_step.shape[0], 20):
                         row = {"Train/Loss": float(per_step[t, 0])}
                         row.update({f"Train/{k}": v for k, v in per_cm.get(t + 1, [{}])[0].items()})
                         self._log(row, step=t + 1)
-                self._log_phase("Train", out["Train"]["loss"][0], out["Train"]["confusion"][0], self._local_step)
+                self._log_phase("Train", out["Train"]["loss"][0], out["Train"]["confusion"][0] if clsf else None,
+                                self._local_step)
                 if "Validation" in out:
-                    self._log_phase("Validation", out["Validation"]["loss"][0], out["Validation"]["confusion"][0],
-                                    self._local_step)
+                    self._log_phase("Validation", out["Validation"]["loss"][0],
+                                    out["Validation"]["confusion"][0] if clsf else None, self._local_step)
                 return
             self.model.to(self.device)
             self._optimizer = self.model.configure_optimizers()
@@ -287,7 +289,7 @@ class LightningLearner(NodeLearner):
                 self._model_to_engine(eng)
                 out = eng.evaluate()
                 eng.synchronize()
-                loss, cm = float(out["loss"][0]), out["confusion"][0]
+                loss, cm = float(out["loss"][0]), (out["confusion"][0] if getattr(self.model, "is_classifier", True) else None)
             else:
                 self.model.to(self.device)
                 loss, cm, _ = self._run_loader(self.data.test_dataloader(), "Test", False)

@@ -7,11 +7,13 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from .....models import specs
 from .....models.torch_models import FederatedModule
 
 
 class SyscallModelAutoencoder(FederatedModule):
     is_classifier = False
+    spec_factory = staticmethod(specs.syscall_autoencoder)    # client-batched HIP kernels (loss: csrc/loss.hip, mse_input)
 
     def __init__(self, in_channels=17, out_channels=9, learning_rate=1e-2, metrics=None, confusion_matrix=None,
                  seed=None):

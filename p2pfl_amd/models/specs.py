@@ -9,6 +9,7 @@ Reference architectures:
 * MNIST CNN      – fedstellar/learning/pytorch/mnist/models/cnn.py:134-164 (its ``forward`` returns
   the input instead of the logits, cnn.py:159; this build returns logits)
 * FEMNIST CNN    – fedstellar/learning/pytorch/femnist/models/cnn.py:136-157
+* SYSCALL auto-encoder – fedstellar/learning/pytorch/syscall/models/autoencoder.py (six linear layers, MSE against the input)
 * WADI MLP       – fedstellar/learning/pytorch/wadi/models/mlp.py (nine linear layers, ReLU between, ONE logit through a
   sigmoid + BCELoss = the two-class problem the loss kernel solves for C = 1)
 """
@@ -63,6 +64,8 @@ class ModelSpec:
     optim: OptimSpec
     num_classes: int
     input_shape: Tuple[int, int, int] = (1, 28, 28)
+    loss: str = "ce"          # "ce": softmax cross-entropy over the last layer's outputs (ONE output: sigmoid + BCE);
+    #                           "mse_input": reconstruction error against the input batch (auto-encoders: no class metrics)
 
     @property
     def num_params(self) -> int:
@@ -160,7 +163,20 @@ def wadi_mlp(num_classes: int = 1, lr: float = 1e-3) -> ModelSpec:
                      num_classes=2, input_shape=(1, 1, 123))
 
 
+def syscall_autoencoder(num_classes: int = 9, lr: float = 1e-2) -> ModelSpec:
+    """17 -> 64 -> 16 -> 8 -> 16 -> 64 -> 17, ReLU after all but the last layer, MSE against the input, Adam
+    (reference syscall/models/autoencoder.py). ``num_classes`` = classes of the data set's labels (unused by the loss)."""
+    dims = (17, 64, 16, 8, 16, 64, 17)
+    params, layers = [], []
+    for i in range(6):
+        params += [ParamSpec(f"fc{i + 1}.weight", (dims[i + 1], dims[i])), ParamSpec(f"fc{i + 1}.bias", (dims[i + 1],))]
+        layers.append(LayerSpec("linear", f"fc{i + 1}.weight", f"fc{i + 1}.bias", dims[i], dims[i + 1], relu=i < 5))
+    return ModelSpec(name="syscall-autoencoder", params=tuple(params), layers=tuple(layers), optim=OptimSpec("adam", lr),
+                     num_classes=max(int(num_classes), 2), input_shape=(1, 1, 17), loss="mse_input")
+
+
 SPECS = {
+    "syscall-autoencoder": syscall_autoencoder,
     "wadi-mlp": wadi_mlp,
     "mnist-mlp": mnist_mlp,
     "mnist-cnn": mnist_cnn,

@@ -173,9 +173,10 @@ class FederatedModule(nn.Module):
 _LAZY = {"MNISTModelMLP": "p2pfl_amd.learning.pytorch.mnist.models.mlp",
          "MNISTModelCNN": "p2pfl_amd.learning.pytorch.mnist.models.cnn",
          "FEMNISTModelCNN": "p2pfl_amd.learning.pytorch.femnist.models.cnn",
-         "WADIModelMLP": "p2pfl_amd.learning.pytorch.wadi.models.mlp"}
+         "WADIModelMLP": "p2pfl_amd.learning.pytorch.wadi.models.mlp",
+         "SyscallModelAutoencoder": "p2pfl_amd.learning.pytorch.syscall.models.autoencoder"}
 _BY_SPEC = {"mnist-mlp": "MNISTModelMLP", "mnist-cnn": "MNISTModelCNN", "femnist-cnn": "FEMNISTModelCNN",
-            "wadi-mlp": "WADIModelMLP"}
+            "wadi-mlp": "WADIModelMLP", "syscall-autoencoder": "SyscallModelAutoencoder"}
 
 
 def __getattr__(name):

@@ -136,6 +136,7 @@ class _Sig:
     p2pfl_conv2_wgrad_scratch = [I, I, I, I]
     p2pfl_conv2_dgrad = [P, L, P, L, P, L, P, L, I, I, I, I, I, I, I, P]
     p2pfl_softmax_ce = [P, L, P, L, P, L, P, L, P, P, P, P, P, L, I, I, I, P]
+    p2pfl_mse_input = [P, L, P, L, P, L, P, L, P, P, P, L, I, I, I, P]
     p2pfl_zero_rows = [P, L, I, I, P]
     p2pfl_adam_step = [P, P, P, P, L, L, L, I, F, F, F, F, F, I, P, P]
     p2pfl_adam_step2 = [P, P, P, P, L, L, L, L, I, F, F, F, F, F, I, P, P]
@@ -526,6 +527,19 @@ def linear_head(x, w, b, labels, sidx, loss_sum, correct, count, confusion=None,
                                   _t(count, torch.int32).data_ptr(),
                                   None if confusion is None else _t(confusion, torch.int32).data_ptr(),
                                   nvp, nvs, K, B, In, C, int(relu_mask), _optp(opt), _stream()), "linear_head")
+
+
+def mse_input(out, data, sidx, dout, loss_sum, count, n_valid=None) -> None:
+    """Reconstruction loss fwd/bwd of the auto-encoders: MSE between ``out`` [K,B,D] and the batch's INPUT rows, gathered
+    from ``data`` [K,n,D] with ``sidx`` [K,B] (None: rows 0..B-1). ``dout`` None: evaluation. ``loss_sum`` += mean loss
+    of the batch x its samples, ``count`` += samples."""
+    K, B, D = out.shape
+    if data.shape[2] != D or data.stride(1) != D:
+        raise HipKernelError(f"mse_input: data rows of {data.shape[2]} (stride {data.stride(1)}) for outputs of {D}")
+    (op, os_), (xp, xs), (sp, ss), (dp, ds) = _pc(out), _pc(data), _pc(sidx, torch.int32), _pc(dout)
+    nvp, nvs = _pc(n_valid, torch.int32)
+    _chk(load().p2pfl_mse_input(op, os_, xp, xs, sp, ss, dp, ds, _t(loss_sum).data_ptr(),
+                                _t(count, torch.int32).data_ptr(), nvp, nvs, K, B, D, _stream()), "mse_input")
 
 
 def zero_rows(t) -> None:

@@ -132,6 +132,8 @@ class ShardEngine:
         self._step_log = torch.zeros(total, 2, self.K, device=self.device)
         logged = [p for p in range(total) if (p + 1) % self.LOG_EVERY == 0]
         self._cm_slot = {p: i for i, p in enumerate(sorted({q for p in logged for q in (p - 1, p)}))}
+        if getattr(self.spec, "loss", "ce") != "ce":
+            self._cm_slot = {}                        # no class metrics to derive: the loss series only
         C = self.stats["Train"].confusion.shape[-1]
         self._step_cm = torch.zeros(max(len(self._cm_slot), 1), self.K, C, C, dtype=torch.int32, device=self.device)
         return True
@@ -343,9 +345,10 @@ class EagerEngine(ShardEngine):
                 with torch.no_grad():
                     loss, pred = m.training_loss(xb, yb)
             st.loss_sum[k] += loss.detach() * len(idx)
-            st.correct[k] += (pred == yb).sum().to(torch.int32)
             st.count[k] += len(idx)
-            st.confusion[k].view(-1).index_add_(0, (yb * C + pred), torch.ones_like(pred, dtype=torch.int32))
+            if pred is not None:                             # (None: a family without classes - the auto-encoder)
+                st.correct[k] += (pred == yb).sum().to(torch.int32)
+                st.confusion[k].view(-1).index_add_(0, (yb * C + pred), torch.ones_like(pred, dtype=torch.int32))
             if train:
                 self._record_client_step(step0 + s // self.B, k)
 
@@ -520,7 +523,7 @@ class HipEngine(ShardEngine):
         ll = self.spec.layers[last]
         # (one workgroup per client: below ~32 clients the kernel leaves most of the chip idle and the four small
         # kernels it replaces are faster - 10 clients: 86 us per step against 44; P2PFL_HEAD_MIN_K overrides)
-        if (ll.kind == "linear" and last > 0 and not ll.relu and last not in self._fused
+        if (ll.kind == "linear" and last > 0 and not ll.relu and last not in self._fused and self.spec.loss == "ce"
                 and not os.environ.get("P2PFL_NO_HEAD") and K >= int(os.environ.get("P2PFL_HEAD_MIN_K", "32"))
                 and hip.linear_head_accepts(B, ll.in_features, ll.out_features)):
             self._head = last
@@ -730,8 +733,12 @@ class HipEngine(ShardEngine):
                     self._linear_fwd(x.flatten(2) if x.dim() > 3 else x, W, b, act[i], l.relu)
             x = act[i]
         st = self.stats[phase]
-        hip.softmax_ce(x, labels, sidx, self.dact[-1] if train else None, st.loss_sum, st.correct, st.count,
-                       st.confusion, n_valid)
+        if self.spec.loss == "mse_input":      # auto-encoder: reconstruction error against the batch's own input rows
+            hip.mse_input(x, data if sidx is not None else data[:, :B], sidx, self.dact[-1] if train else None,
+                          st.loss_sum, st.count, n_valid)
+        else:
+            hip.softmax_ce(x, labels, sidx, self.dact[-1] if train else None, st.loss_sum, st.correct, st.count,
+                           st.confusion, n_valid)
         if train:
             self._record_step()
 

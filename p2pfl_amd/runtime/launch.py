@@ -36,10 +36,10 @@ from ..parallel.planner import locality_placement, placement_order
 from .federation import BatchedFederation
 
 _SPEC_OF = {("MNIST", "MLP"): "mnist-mlp", ("MNIST", "CNN"): "mnist-cnn", ("FEMNIST", "CNN"): "femnist-cnn",
-            ("WADI", "MLP"): "wadi-mlp"}
+            ("WADI", "MLP"): "wadi-mlp", ("SYSCALL", "Autoencoder"): "syscall-autoencoder"}
 # on the CPU these families stay on the client-batched stock-op engine (one vmap step for all nodes) instead of the
 # per-node loop that is the CPU side of a kernel-level spec
-_GPU_ONLY_SPECS = {("WADI", "MLP")}
+_GPU_ONLY_SPECS = {("WADI", "MLP"), ("SYSCALL", "Autoencoder")}
 
 
 def load_participants(config_dir: str) -> List[dict]:

@@ -182,6 +182,49 @@ def test_wadi_mlp_trains_on_the_kernels_like_the_eager_engine(precision):
     assert bool(torch.isfinite(h2.params).all())
 
 
+def test_syscall_autoencoder_trains_on_the_kernels_like_the_eager_engine():
+    """Fifth family with a kernel-level spec: 17 -> 64 -> 16 -> 8 -> 16 -> 64 -> 17 with the reconstruction loss kernel
+    (MSE against the batch's own input rows) - first-step gradients and whole fits against the nn.Module under autograd;
+    no class metrics (per-step tables carry the loss only)."""
+    from p2pfl_amd.models.specs import get_spec
+    from p2pfl_amd.runtime.engine import EagerEngine, HipEngine
+    spec = get_spec("syscall-autoencoder")
+    K, n, B = 3, 80, 32                              # 80 = 2 full batches + a tail of 16
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(K, n, 17, generator=g)
+    y = torch.randint(0, 9, (K, n), generator=g)
+    data = [t.cuda() for t in (x, y, x[:, :24], y[:, :24], x[:, :40], y[:, :40])]
+    h = HipEngine(spec, K, "cuda", seed=11, use_graph=False, fuse_optimizer=False)
+    e = EagerEngine(spec, K, "cuda", seed=11)
+    h.init_params(identical=False)
+    e.params.copy_(h.params)
+    h.set_data(*data); e.set_data(*data)
+    sidx = torch.stack([torch.randperm(n, device="cuda")[:B] for _ in range(K)]).int()
+    h.stats["Train"].zero_()
+    h._forward(h.train_x, sidx, h.train_y, h._nv(B), "Train", train=True)
+    h._backward(h.train_x, sidx)
+    torch.cuda.synchronize()
+    for k in range(K):
+        m = e.modules[k]
+        m.zero_grad()
+        loss, pred = m.training_loss(e.train_x[k][sidx[k].long()], None)
+        loss.backward()
+        assert pred is None and abs(h.stats["Train"].loss_sum[k].item() / B - loss.item()) < 1e-6
+        for pname, p_ in m.named_parameters():
+            err = (h.grad_view(pname)[k] - p_.grad).norm() / p_.grad.norm().clamp(min=1e-12)
+            assert err < 1e-4, f"{pname}: rel err {err:.3e}"
+    h2 = HipEngine(spec, K, "cuda", seed=11, log_steps=True)
+    h2.params.copy_(e.params)
+    h2.set_data(*data)
+    t0 = e.evaluate()["loss"].clone()
+    o_h, o_e = h2.fit(3), e.fit(3)
+    t_h, t_e = h2.evaluate(), e.evaluate()
+    assert torch.allclose(o_h["Train"]["loss"].cpu(), o_e["Train"]["loss"].cpu(), atol=1e-4)
+    assert torch.allclose(o_h["Validation"]["loss"].cpu(), o_e["Validation"]["loss"].cpu(), atol=1e-4)
+    assert torch.allclose(t_h["loss"].cpu(), t_e["loss"].cpu(), atol=1e-4) and bool((t_h["loss"].cpu() < t0.cpu()).all())
+    assert int(t_h["confusion"].sum()) == 0 and h2.step_losses().shape == (9, K) and h2.step_metrics() == {}
+
+
 def test_prepare_leaves_no_trace():
     """prepare() captures the graphs with a dry-run round; training afterwards == training without it."""
     from p2pfl_amd.datasets.synthetic import synthetic_shards

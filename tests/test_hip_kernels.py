@@ -468,13 +468,37 @@ def test_sigmoid_bce_for_one_logit_models(B, nv):
         z = logits[k, :nv, 0].clone().requires_grad_(True)
         ref = F.binary_cross_entropy(torch.sigmoid(z), y, reduction="sum")        # the reference's own formulation
         (F.binary_cross_entropy_with_logits(z, y, reduction="sum") / nv).backward()
-        assert torch.isfinite(loss[k]) and torch.allclose(loss[k], ref.detach(), rtol=1e-4, atol=1e-3)
+        exact = F.binary_cross_entropy_with_logits(z.detach().double(), y.double(), reduction="none").clamp(max=100).sum()
+        assert torch.isfinite(loss[k]) and torch.allclose(loss[k].double(), exact, rtol=1e-5)
+        assert torch.allclose(loss[k], ref.detach(), rtol=1e-3)     # (sigmoid saturates in fp32: the reference form is the loose one)
         assert torch.allclose(dl[k, :nv, 0], z.grad, atol=1e-6, rtol=1e-4) and (dl[k, nv:] == 0).all()
         pred = (logits[k, :nv, 0] > 0).long()
         assert corr[k].item() == (pred == y.long()).sum().item() and cnt[k].item() == nv
         ref_cm = torch.zeros(4, dtype=torch.int32, device=DEV).index_add_(
             0, y.long() * 2 + pred, torch.ones(nv, dtype=torch.int32, device=DEV)).view(2, 2)
         assert (cm[k] == ref_cm).all()
+
+
+@pytest.mark.parametrize("B,nv,D,gather", [(32, 32, 17, True), (32, 21, 17, True), (96, 96, 17, False), (8, 5, 40, True)])
+def test_mse_against_the_input_batch(B, nv, D, gather):
+    """Reconstruction loss of the auto-encoders (syscall/models/autoencoder.py: MSELoss(decoder output, input))."""
+    h = hip()
+    K, n = 3, 120
+    data = torch.randn(K, n, D, device=DEV)
+    out = torch.randn(K, B, D, device=DEV)
+    sidx = torch.stack([torch.randperm(n, device=DEV)[:B] for _ in range(K)]).int() if gather else None
+    dout = torch.full_like(out, 7.0)
+    loss = torch.zeros(K, device=DEV)
+    cnt = torch.zeros(K, dtype=torch.int32, device=DEV)
+    h.mse_input(out, data, sidx, dout, loss, cnt, torch.full((K,), nv, dtype=torch.int32, device=DEV))
+    h.mse_input(out, data, sidx, None, loss, cnt, torch.full((K,), nv, dtype=torch.int32, device=DEV))   # evaluation form
+    for k in range(K):
+        x = (data[k][sidx[k].long()] if gather else data[k, :B])[:nv]
+        o = out[k, :nv].clone().requires_grad_(True)
+        ref = F.mse_loss(o, x)
+        ref.backward()
+        assert torch.allclose(loss[k], 2 * ref.detach() * nv, rtol=1e-5) and cnt[k].item() == 2 * nv
+        assert torch.allclose(dout[k, :nv], o.grad, atol=1e-7, rtol=1e-5) and (dout[k, nv:] == 0).all()
 
 
 def test_adam_two_ranges_in_one_launch_match_torch_and_leave_the_gap_alone():

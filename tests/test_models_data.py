@@ -532,3 +532,28 @@ def test_wadi_mlp_has_a_kernel_level_spec():
     out = eng.fit(3)
     assert out["Train"]["confusion"].shape == (2, 2, 2) and int(out["Train"]["count"][0]) == 64
     assert bool((eng.evaluate()["loss"] < l0).all())
+
+
+def test_syscall_autoencoder_has_a_kernel_level_spec():
+    """The auto-encoder's spec: state_dict order, MSE-against-the-input loss, and its CPU side (EagerEngine through the
+    module's own training_loss: no predictions, so no class counters)."""
+    from p2pfl_amd.learning.pytorch.syscall.models.autoencoder import SyscallModelAutoencoder
+    from p2pfl_amd.models.specs import get_spec
+    from p2pfl_amd.runtime.engine import EagerEngine
+    from p2pfl_amd.runtime.launch import _GPU_ONLY_SPECS, _SPEC_OF
+    spec, m = get_spec("syscall-autoencoder"), SyscallModelAutoencoder()
+    sd = m.state_dict()
+    assert [p.name for p in spec.params] == list(sd) and all(tuple(sd[p.name].shape) == p.shape for p in spec.params)
+    assert spec.loss == "mse_input" and m.spec.name == "syscall-autoencoder" and get_spec("mnist-cnn").loss == "ce"
+    assert [l.relu for l in spec.layers] == [True] * 5 + [False]
+    assert _SPEC_OF[("SYSCALL", "Autoencoder")] == "syscall-autoencoder" and ("SYSCALL", "Autoencoder") in _GPU_ONLY_SPECS
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(2, 48, 17, generator=g)
+    y = torch.randint(0, 9, (2, 48), generator=g)
+    eng = EagerEngine(spec, 2, "cpu", batch_size=16, seed=1, log_steps=True)
+    eng.init_params()
+    eng.set_data(x, y, x[:, :16], y[:, :16], x[:, :32], y[:, :32])
+    l0 = eng.evaluate()["loss"].clone()
+    out = eng.fit(4)
+    assert int(out["Train"]["confusion"].sum()) == 0 and int(out["Train"]["count"][0]) == 48
+    assert bool((eng.evaluate()["loss"] < l0).all()) and eng.step_metrics() == {} and eng.step_losses().shape == (12, 2)

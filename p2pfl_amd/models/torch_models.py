@@ -168,7 +168,7 @@ class FederatedModule(nn.Module):
         return torch.optim.SGD(self.parameters(), lr=o.lr, momentum=o.momentum, weight_decay=o.weight_decay)
 
 
-# The three spec'd families are defined under the reference's module paths; they are resolved lazily here so that either
+# The spec'd families are defined under the reference's module paths; they are resolved lazily here so that either
 # module can be imported first.
 _LAZY = {"MNISTModelMLP": "p2pfl_amd.learning.pytorch.mnist.models.mlp",
          "MNISTModelCNN": "p2pfl_amd.learning.pytorch.mnist.models.cnn",

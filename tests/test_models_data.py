@@ -557,3 +557,40 @@ def test_syscall_autoencoder_has_a_kernel_level_spec():
     out = eng.fit(4)
     assert int(out["Train"]["confusion"].sum()) == 0 and int(out["Train"]["count"][0]) == 48
     assert bool((eng.evaluate()["loss"] < l0).all()) and eng.step_metrics() == {} and eng.step_losses().shape == (12, 2)
+
+
+def test_archive_dataset_zip_members_stay_inside_raw_and_cm_tables_reach_the_logger(tmp_path):
+    """dataset_download on a zip archive (the SYSCALL data ships as one): members that would leave raw/ are skipped;
+    log_metrics_by_epoch(plot_cm=True) hands the epoch's confusion matrix to a logger that takes tables."""
+    import zipfile
+    from p2pfl_amd.learning.pytorch.syscall.syscall import FEATURE, SYSCALL
+    arc = tmp_path / "syscall.zip"
+    rows = ["id\t%s\tmaltype" % FEATURE] + ["%d\t%s\t%s" % (i, [0.1 * (i % 5)] * 17, ["normal", "bdvl"][i % 2]) for i in range(20)]
+    with zipfile.ZipFile(arc, "w") as z:
+        z.writestr("a.csv", "\n".join(rows) + "\n")
+        z.writestr("../../evil.csv", "x")
+
+    class Local(SYSCALL):
+        download_link = "file://" + str(arc)
+    ds = Local(root_dir=str(tmp_path / "data"), download=True)
+    assert len(ds) == 17 and ds.classes == ["bdvl", "normal"]
+    assert not (tmp_path / "evil.csv").exists() and not (tmp_path / "data" / "evil.csv").exists()
+    # confusion-matrix table of an epoch
+    _, m = build_dataset_and_model("MNIST", "MLP", 0, 50)
+    tables = []
+
+    class Lg:
+        def log_metrics(self, metrics, step=None):
+            pass
+
+        def log_table(self, key, columns=None, data=None, step=None):
+            tables.append((key, columns, data, step))
+    m.logger = Lg()
+    x, y = torch.randn(6, 1, 28, 28), torch.tensor([0, 1, 2, 3, 4, 5])
+    m.training_step((x, y), 0)
+    m.on_train_epoch_end()
+    key, cols, data, step = tables[0]
+    assert key == "TrainEpoch/CM" and len(cols) == 10 and sum(map(sum, data)) == 6 and step == 0
+    m.training_step((x, y), 0)
+    m.on_train_epoch_end()
+    assert tables[1][3] == 1 and sum(map(sum, tables[1][2])) == 6          # reset between epochs

@@ -29,6 +29,8 @@ def _scenario(tmp_path, n, federation, dataset, model, rounds, topology="ring"):
 @pytest.mark.parametrize("dataset,model,federation,topology", [("MNIST", "CNN", "DFL", "ring"),
                                                                ("MNIST", "MLP", "CFL", "star"),
                                                                ("FEMNIST", "CNN", "SDFL", "ring"),
+                                                               ("WADI", "MLP", "DFL", "ring"),            # one logit: BCE kernel
+                                                               ("SYSCALL", "Autoencoder", "DFL", "ring"),  # reconstruction loss
                                                                # no kernel-level spec: stock ops, state in the slab
                                                                ("SYSCALL", "MLP", "DFL", "ring"),
                                                                ("CIFAR10", "simplemobilenet", "DFL", "ring")])

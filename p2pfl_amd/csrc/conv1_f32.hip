@@ -16,6 +16,7 @@
 //
 // Reference layers: fedstellar/learning/pytorch/mnist/models/cnn.py:134-138,151-152 (5x5),
 // fedstellar/learning/pytorch/femnist/models/cnn.py:136,147 (7x7).
+#include <cstdlib>
 #include "conv_f32.h"
 
 namespace {
@@ -357,10 +358,17 @@ int conv1_wgrad_f32(const float* g, long g_cs, const uint8_t* code, long c_cs, c
     return conv1_wgrad_finish(scratch, splits * 4, njn, /*tap8=*/0, dw, dw_cs, db, db_cs, K, F, KS, opt, stream);
 }
 
-// blocks per client - matrix-pipe-bound: about two blocks per CU over the launch, at most one per image
+// blocks per client - matrix-pipe-bound: about two blocks per CU over the launch, and a block keeps >= 2 images to amortise
+// its prologue (10 clients: 16 blocks per client 34 / 25 us for 7x7 / 5x5, 32: 35 / 27; cnn10-fully 317.2 -> 314.8 ms).
+// Alone the kernel would like to stay within the 512 resident blocks (50 clients: 10 per client 78 us, 11: 97 us;
+// tools/probe/c1w_splits.sh, P2PFL_C1W_SPLITS forces a count) but inside the step it runs beside the stage-2 weight
+// gradient of the side stream and the finer split wins there: femnist50-ring 5: 60.4 ms, 8: 56.4, 10: 58.7 against 57.8
+// for 11 on the same box, 11: 55.2, 12: 55.2, 16: 56.2, 32: 56.6 - the rule stays ceil(512 / K).
 int conv1_wgrad_f32_splits(int K, int B) {
+    static const int forced = [] { const char* e = getenv("P2PFL_C1W_SPLITS"); return e ? atoi(e) : 0; }();
+    if (forced > 0) return forced > B ? B : forced;
     int splits = cdiv(512, K);
-    if (splits > B) splits = B;
+    if (splits > (B + 1) / 2) splits = (B + 1) / 2;
     if (splits < 1) splits = 1;
     return splits;
 }

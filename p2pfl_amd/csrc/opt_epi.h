@@ -51,6 +51,22 @@ struct OptEpi {
             *p = pv - lr * bv;
         }
     }
+    // the same step with the parameter / moment values already in registers (loaded early, beside the operands of the
+    // gradient): operation for operation apply()
+    __device__ __forceinline__ void apply_loaded(const Scal& s, float* p, float* m, float* v, float pv, float m0, float v0,
+                                                 float g) const {
+        const float gr = g + wd * pv;
+        if (kind == 1) {
+            const float mv = beta1 * m0 + (1.f - beta1) * gr;
+            const float vv = beta2 * v0 + (1.f - beta2) * gr * gr;
+            *m = mv; *v = vv;
+            *p = pv - s.step * (mv / (sqrtf(vv) * s.isb2 + eps));
+        } else {
+            const float bv = momentum * m0 + gr;
+            *m = bv;
+            *p = pv - lr * bv;
+        }
+    }
     __device__ __forceinline__ void weight(const Scal& s, int client, long i, float g) const {
         const long o = client * cs + i;
         apply(s, pw + o, mw + o, vw ? vw + o : nullptr, g);

@@ -127,7 +127,8 @@ class _Sig:
     p2pfl_conv1_wgrad = [P, L, P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, P, P]
     p2pfl_conv1_wgrad_scratch = [I, I, I, I]
     p2pfl_conv2_wgrad_opt = [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, I, I, I, I, P, P]
-    p2pfl_linear_head = [P, L, P, L, P, L, P, L, P, L, P, L, P, L, P, L, P, L, P, P, P, P, P, L, I, I, I, I, I, P, P]
+    p2pfl_linear_head = [P, L, P, L, P, L, P, L, P, L, P, L, P, L, P, L, P, L, P, P, P, P, P, L, I, I, I, I, I, P, P, L, P]
+    p2pfl_linear_head_scratch = [I, I, I, I]
     p2pfl_linear_head_accepts = [I, I, I]
     p2pfl_linear_wgrad_adam_dgrad_accepts = [I, I, I, I]
     p2pfl_conv2_prep = [P, L, P, L, I, I, I, I, I, P]
@@ -509,12 +510,21 @@ def linear_head_accepts(B: int, In: int, C: int) -> bool:
     return bool(load().p2pfl_linear_head_accepts(B, In, C))
 
 
+def linear_head_scratch(K: int, B: int, In: int, C: int, device) -> Optional[torch.Tensor]:
+    """Scratch buffer with which :func:`linear_head` takes its two-kernel form over (client, column slice) grids (wide
+    heads: In >= 1024); None: the one-kernel form covers this shape."""
+    need = int(load().p2pfl_linear_head_scratch(K, B, In, C))
+    return torch.empty(need, dtype=torch.float32, device=device) if need else None
+
+
 def linear_head(x, w, b, labels, sidx, loss_sum, correct, count, confusion=None, n_valid=None, *, dx=None, dw=None,
-                db=None, logits=None, relu_mask: bool = False, opt: Optional[OptStruct] = None) -> None:
-    """The classification head of a training step in one kernel per client (csrc/head.hip): logits = x w^T + b,
-    softmax cross-entropy + metric counters, ``dx = (dlogits w) * [x > 0 if relu_mask]``, and either the gradients
-    ``dw`` / ``db`` or - with ``opt`` (:func:`fold_opt` over these very ``w`` / ``b`` views) - the optimizer step in
-    place. x [K,B,In] (B <= 32), w [K,C,In] (C <= 16), b [K,C], labels [K,n] int32, dx [K,B,In] or None."""
+                db=None, logits=None, relu_mask: bool = False, opt: Optional[OptStruct] = None,
+                scratch: Optional[torch.Tensor] = None) -> None:
+    """The classification head of a training step (csrc/head.hip): logits = x w^T + b, softmax cross-entropy + metric
+    counters, ``dx = (dlogits w) * [x > 0 if relu_mask]``, and either the gradients ``dw`` / ``db`` or - with ``opt``
+    (:func:`fold_opt` over these very ``w`` / ``b`` views) - the optimizer step in place. One kernel per client, or
+    - with ``scratch`` from :func:`linear_head_scratch` - two kernels over column slices of the clients.
+    x [K,B,In] (B <= 32), w [K,C,In] (C <= 16), b [K,C], labels [K,n] int32, dx [K,B,In] or None."""
     K, B, In = x.shape
     C = w.shape[1]
     assert w.shape == (K, C, In) and b.shape == (K, C)
@@ -526,7 +536,9 @@ def linear_head(x, w, b, labels, sidx, loss_sum, correct, count, confusion=None,
                                   _t(loss_sum).data_ptr(), _t(correct, torch.int32).data_ptr(),
                                   _t(count, torch.int32).data_ptr(),
                                   None if confusion is None else _t(confusion, torch.int32).data_ptr(),
-                                  nvp, nvs, K, B, In, C, int(relu_mask), _optp(opt), _stream()), "linear_head")
+                                  nvp, nvs, K, B, In, C, int(relu_mask), _optp(opt),
+                                  None if scratch is None else scratch.data_ptr(),
+                                  0 if scratch is None else scratch.numel(), _stream()), "linear_head")
 
 
 def mse_input(out, data, sidx, dout, loss_sum, count, n_valid=None) -> None:

@@ -521,12 +521,15 @@ class HipEngine(ShardEngine):
         self._head = None
         last = len(self.spec.layers) - 1
         ll = self.spec.layers[last]
-        # (one workgroup per client: below ~32 clients the kernel leaves most of the chip idle and the four small
-        # kernels it replaces are faster - 10 clients: 86 us per step against 44; P2PFL_HEAD_MIN_K overrides)
+        # Two forms (csrc/head.hip). Wide heads (In >= 1024) take two kernels over (client, column slice) grids at any
+        # client count. Narrow ones take the one-kernel form, one workgroup per client: below ~32 clients that leaves
+        # most of the chip idle and the four small kernels it replaces are faster (P2PFL_HEAD_MIN_K overrides).
+        self._head_scratch = None
         if (ll.kind == "linear" and last > 0 and not ll.relu and last not in self._fused and self.spec.loss == "ce"
-                and not os.environ.get("P2PFL_NO_HEAD") and K >= int(os.environ.get("P2PFL_HEAD_MIN_K", "32"))
-                and hip.linear_head_accepts(B, ll.in_features, ll.out_features)):
-            self._head = last
+                and not os.environ.get("P2PFL_NO_HEAD") and hip.linear_head_accepts(B, ll.in_features, ll.out_features)):
+            self._head_scratch = hip.linear_head_scratch(K, B, ll.in_features, ll.out_features, dev)
+            if self._head_scratch is not None or K >= int(os.environ.get("P2PFL_HEAD_MIN_K", "32")):
+                self._head = last
         if o.kind in ("adam", "sgd") and fuse_optimizer and not os.environ.get("P2PFL_NO_FUSE") \
                 and not os.environ.get("P2PFL_NO_FOLD"):
             for i, l in enumerate(self.spec.layers):
@@ -898,7 +901,7 @@ class HipEngine(ShardEngine):
         dx = self.dact[i - 1].flatten(2) if self.dact[i - 1].dim() > 3 else self.dact[i - 1]
         self.hip.linear_head(x.flatten(2) if x.dim() > 3 else x, W, b, labels, sidx, st.loss_sum, st.correct, st.count,
                              st.confusion, n_valid, dx=dx, dw=gW, db=gb,
-                             relu_mask=prev.kind == "linear" and prev.relu, opt=opt)
+                             relu_mask=prev.kind == "linear" and prev.relu, opt=opt, scratch=self._head_scratch)
         self._record_step()
 
     def _optim_step(self, step_index: int) -> None:

@@ -838,11 +838,17 @@ def _slabs(K, P, n=3):
 @pytest.mark.parametrize("K,B,nv,In,C,mask", [(3, 32, 32, 2048, 10, True), (2, 32, 12, 128, 10, True),
                                               (2, 20, 20, 3136, 16, False), (5, 7, 5, 260, 3, True)])
 @pytest.mark.parametrize("kind", [None, "adam", "sgd"])
-def test_linear_head_matches_torch(K, B, nv, In, C, mask, kind):
+@pytest.mark.parametrize("form", ["one-kernel", "sliced"])
+def test_linear_head_matches_torch(K, B, nv, In, C, mask, kind, form):
     """csrc/head.hip against autograd: logits, loss / accuracy / confusion counters, data gradient with the ReLU mask,
-    and either the parameter gradients or one step of torch.optim on (W, b)."""
+    and either the parameter gradients or one step of torch.optim on (W, b) - the one-kernel form and the two-kernel
+    form over column slices (wide heads, with the caller's scratch)."""
     h = hip()
     assert h.linear_head_accepts(B, In, C)
+    scratch = h.linear_head_scratch(K, B, In, C, DEV) if form == "sliced" else None
+    assert (scratch is not None) == (form == "sliced" and In >= 1024)
+    if form == "sliced" and scratch is None:
+        return          # narrow heads have the one form only (covered by the other parameter)
     n = 50
     P = C * In
     off_b = -(-P // 64) * 64
@@ -868,11 +874,11 @@ def test_linear_head_matches_torch(K, B, nv, In, C, mask, kind):
     if kind is None:
         g = torch.zeros_like(p)
         h.linear_head(x, W(p), Bv(p), labels, sidx, loss_sum, correct, count, conf, nvt, dx=dx, dw=W(g), db=Bv(g),
-                      logits=logits, relu_mask=mask)
+                      logits=logits, relu_mask=mask, scratch=scratch)
     else:
         opt = h.fold_opt(kind, W(p), W(m), W(v), Bv(p), Bv(m), Bv(v), momentum=0.9, t=t, **hyper)
         h.linear_head(x, W(p), Bv(p), labels, sidx, loss_sum, correct, count, conf, nvt, dx=dx, logits=logits,
-                      relu_mask=mask, opt=opt)
+                      relu_mask=mask, opt=opt, scratch=scratch)
     torch.cuda.synchronize()
     for k in range(K):
         w_ref = W(p0)[k].clone().requires_grad_(True)
@@ -915,6 +921,36 @@ def test_linear_head_matches_torch(K, B, nv, In, C, mask, kind):
             assert rel_err(W(v)[k], st["exp_avg_sq"]) < 2e-5
     # nothing outside the layer's columns moved
     assert torch.equal(p[:, P:off_b], p0[:, P:off_b]) and torch.equal(p[:, off_b + C:], p0[:, off_b + C:])
+
+
+def test_sliced_head_bits_do_not_depend_on_the_shard_size():
+    """The column slices of the two-kernel head are a function of the layer width only: clients 0..2 of a 7-client launch
+    end with the very bits a 3-client launch gives them (client groups of one round run shards of different sizes)."""
+    h = hip()
+    B, In, C, n = 32, 2048, 10, 40
+    P = C * In
+    off_b = -(-P // 64) * 64
+    torch.manual_seed(5)
+    base = _slabs(7, off_b + 64)
+    base[1].abs_(); base[2].abs_()
+    x = torch.randn(7, B, In, device=DEV).relu()
+    labels = torch.randint(0, C, (7, n), device=DEV).int()
+    W = lambda s: s[:, :P].unflatten(1, (C, In))
+    Bv = lambda s: s[:, off_b:off_b + C]
+    out = {}
+    for K in (7, 3):
+        p, m, v = (t[:K].clone() for t in base)
+        dx = torch.zeros(K, B, In, device=DEV)
+        stats = (torch.zeros(K, device=DEV), torch.zeros(K, dtype=torch.int32, device=DEV),
+                 torch.zeros(K, dtype=torch.int32, device=DEV))
+        opt = h.fold_opt("adam", W(p), W(m), W(v), Bv(p), Bv(m), Bv(v), lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
+                         weight_decay=0.0, momentum=0.0, t=2)
+        h.linear_head(x[:K], W(p), Bv(p), labels[:K], None, *stats, None, None, dx=dx, relu_mask=True, opt=opt,
+                      scratch=h.linear_head_scratch(K, B, In, C, DEV))
+        torch.cuda.synchronize()
+        out[K] = (p, m, v, dx, stats[0])
+    for a, b in zip(out[7], out[3]):
+        assert torch.equal(a[:3], b)
 
 
 @pytest.mark.parametrize("kind", ["adam", "sgd"])

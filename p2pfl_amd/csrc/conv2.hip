@@ -279,6 +279,184 @@ __global__ __launch_bounds__(256, 2) void conv2_fwd_kernel(FwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// forward, exact-split policy, DENSE window order.
+//
+// The kernel above gives a row tile to one window row: 7 windows on 8 slots, 7 tiles issued as 8 over the four waves -
+// 196 of 256 issued rows are real (76.6 %), and its tap loop is ~80 % matrix-pipe-bound. Here the 49 pool windows of the
+// sample are numbered densely (W = 7 wy + wx, rows m = 4 W + q): six full 32-row tiles (windows 0..47) and ONE window
+// left over. The twelve (tile, 32-column half) units are dealt three to a wave, so a wave reads the weight fragments of
+// one column half only, and the left-over window runs on v_mfma_f32_16x16x32_bf16 (rows 0..3 real, one 16-column tile
+// per wave, all 32 input channels in one instruction). Matrix-pipe time per tap and wave: 36 x 32 + 6 x 16 = 1248
+// cycles against 48 x 32 = 1536.
+// LDS: the chunk rotation of a pixel is ((X >> 1) - (Y >> 1)) & 3 = (W + const) & 3 for the pixels that the four windows
+// of a 16-lane group read for one tap - four consecutive windows, four different rotations, whatever the window row - and
+// the four pixels of a window differ in the 64-byte slot: 16 different 16-byte slots per group, as before.
+// ---------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256, 2) void conv2_fwd_dense_kernel(FwdArgs a) {
+    using G = Geo<KS>;
+    constexpr int NS = 3;
+    constexpr int IMG = G::XSS;                // bytes of one term's image
+    constexpr int WSL = COUT * 80;             // bytes of one term's weight slice
+    constexpr int PLANE = 2 * G::T * COUT * CIN;
+    __shared__ __attribute__((aligned(16))) unsigned char ximg[NS * IMG];
+    __shared__ __attribute__((aligned(16))) unsigned char wbuf[NS * WSL];
+
+    int c, b0;
+    if (!xcd_map(a.B, a.K, c, b0)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    // ---- stage the padded image (fp32 NCHW -> bf16 terms, channel-last, rotated chunks)
+    const float* a1 = a.a1 + c * a.a1_cs;
+    for (int task = tid; task < G::IW * G::IW * 4; task += 256) {
+        const int g = task & 3, rr = task >> 2;
+        const int Y = rr / G::IW, X = rr % G::IW;
+        const int y = Y - G::PAD, x = X - G::PAD;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
+        if (y >= 0 && y < P1 && x >= 0 && x < P1) {
+            const float* src = a1 + ((size_t)b0 * CIN + 8 * g) * CELLS1 + y * P1 + x;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = src[i * CELLS1];
+        }
+        bf16x8 tv[NS];
+        split_bf16x8<NS>(v, tv);
+        const int pos = (g + (X >> 1) + 3 * (Y >> 1)) & 3;
+#pragma unroll
+        for (int e = 0; e < NS; ++e)
+            *reinterpret_cast<bf16x8*>(ximg + e * IMG + Y * G::XRS + X * 64 + pos * 16) = tv[e];
+    }
+    const __bf16* wf = a.wp + c * a.wp_cs;
+#pragma unroll
+    for (int e = 0; e < NS; ++e) {
+        const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wf + e * PLANE + tid * 8);
+        *reinterpret_cast<bf16x8*>(wbuf + e * WSL + (tid >> 2) * 80 + (tid & 3) * 16) = w0;
+    }
+    __syncthreads();
+
+    // ---- my units: column half jc, row tiles 3 (wave >> 1) + {0, 1, 2}; my pixel of each tile (padded coordinates of
+    // tap (0, 0)): window 8 tile + (r >> 2), corner q = r & 3
+    const int jc = wave & 1, t0 = 3 * (wave >> 1);
+    int px[3], py[3], abase[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int Wd = 8 * (t0 + i) + (r >> 2);
+        py[i] = 2 * (Wd / P2) + ((r >> 1) & 1);
+        px[i] = 2 * (Wd % P2) + (r & 1);
+        abase[i] = py[i] * G::XRS + px[i] * 64;
+    }
+    // the left-over window (48 = (6, 6)) on the 16-row instruction: lane -> row = lane & 15 (corner (lane & 3), rows >= 4
+    // repeat it), channel chunk lane >> 4; B: column 16 wave + (lane & 15)
+    const int lq = lane & 3, lg = lane >> 4;
+    const int lpy = 12 + (lq >> 1), lpx = 12 + (lq & 1);
+    const int lbase = lpy * G::XRS + lpx * 64;
+    f32x16 acc[3];
+    f32x4 accl = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    int ky = 0, kx = 0;
+#pragma unroll 1
+    for (int t = 0; t < G::T; ++t) {
+        bf16x8 wnext[NS];
+        if (t + 1 < G::T) {
+#pragma unroll
+            for (int e = 0; e < NS; ++e)
+                wnext[e] = *reinterpret_cast<const bf16x8*>(wf + e * PLANE + (t + 1) * COUT * CIN + tid * 8);
+        }
+        const unsigned char* wb = wbuf + (32 * jc + r) * 80 + h * 16;
+        const int tap_off = ky * G::XRS + kx * 64;
+        int rot[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rot[i] = ((px[i] + kx) >> 1) + 3 * ((py[i] + ky) >> 1) + h;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 bf[NS];
+#pragma unroll
+            for (int e = 0; e < NS; ++e) bf[e] = *reinterpret_cast<const bf16x8*>(wb + e * WSL + ks * 32);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int off = abase[i] + tap_off + ((rot[i] + 2 * ks) & 3) * 16;
+                bf16x8 af[NS];
+#pragma unroll
+                for (int e = 0; e < NS; ++e) af[e] = *reinterpret_cast<const bf16x8*>(ximg + e * IMG + off);
+#pragma unroll
+                for (int ea = 0; ea < NS; ++ea)
+#pragma unroll
+                    for (int eb = 0; eb < NS - ea; ++eb)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ea], bf[eb], acc[i], 0, 0, 0);
+            }
+        }
+        {   // left-over window: all 32 channels in one instruction, 16 columns per wave
+            const int lrot = ((lpx + kx) >> 1) + 3 * ((lpy + ky) >> 1) + lg;
+            const int off = lbase + tap_off + (lrot & 3) * 16;
+            const unsigned char* wl = wbuf + (16 * wave + (lane & 15)) * 80 + lg * 16;
+            bf16x8 af[NS], bl[NS];
+#pragma unroll
+            for (int e = 0; e < NS; ++e) {
+                af[e] = *reinterpret_cast<const bf16x8*>(ximg + e * IMG + off);
+                bl[e] = *reinterpret_cast<const bf16x8*>(wl + e * WSL);
+            }
+#pragma unroll
+            for (int ea = 0; ea < NS; ++ea)
+#pragma unroll
+                for (int eb = 0; eb < NS - ea; ++eb)
+                    accl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ea], bl[eb], accl, 0, 0, 0);
+        }
+        __syncthreads();                                 // every wave finished reading the single slice
+        if (t + 1 < G::T) {
+#pragma unroll
+            for (int e = 0; e < NS; ++e)
+                *reinterpret_cast<bf16x8*>(wbuf + e * WSL + (tid >> 2) * 80 + (tid & 3) * 16) = wnext[e];
+        }
+        __syncthreads();
+        if (++kx == KS) { kx = 0; ++ky; }
+    }
+
+    // ---- epilogue: bias + ReLU + 2x2 max-pool + arg-max code from the accumulators, assembled in the idle image buffer
+    // ([64][49] floats + codes = the sample's contiguous piece of a2 / code) and written as 16-byte pieces
+    static_assert(NS * IMG >= COUT * CELLS2 * 5, "output staging must fit into the image buffer");
+    float* out_s = reinterpret_cast<float*>(ximg);
+    uint8_t* code_s = ximg + COUT * CELLS2 * 4;
+    const float* bias = a.bias + c * a.b_cs;
+    auto pool = [&](float v0, float v1, float v2, float v3, float bv, int n, int W) {
+        float best = v0; int q = 0;
+        if (v1 > best) { best = v1; q = 1; }
+        if (v2 > best) { best = v2; q = 2; }
+        if (v3 > best) { best = v3; q = 3; }
+        best += bv;
+        if (!(best > 0.f)) { best = 0.f; q = 4; }
+        out_s[n * CELLS2 + W] = best;
+        code_s[n * CELLS2 + W] = (uint8_t)q;
+    };
+    {
+        const int n = 32 * jc + r;
+        const float bv = bias[n];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                pool(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3], bv, n, 8 * (t0 + i) + 2 * g + h);
+    }
+    if (lane < 16) {     // 16 x 16 accumulator: lane = column, rows 4 (lane >> 4) + reg -> lanes 0..15 hold window 48
+        const int n = 16 * wave + lane;
+        pool(accl[0], accl[1], accl[2], accl[3], bias[n], n, CELLS2 - 1);
+    }
+    __syncthreads();
+    float* a2 = a.a2 + c * a.a2_cs + (size_t)b0 * COUT * CELLS2;
+    uint8_t* code = a.code + c * a.c_cs + (size_t)b0 * COUT * CELLS2;
+    for (int i = tid; i < COUT * CELLS2 / 4; i += 256)
+        reinterpret_cast<f32x4*>(a2)[i] = reinterpret_cast<const f32x4*>(out_s)[i];
+    for (int i = tid; i < COUT * CELLS2 / 16; i += 256)
+        reinterpret_cast<f32x4*>(code)[i] = reinterpret_cast<const f32x4*>(code_s)[i];
+}
+
+// ---------------------------------------------------------------------------------------
 // data gradient
 // ---------------------------------------------------------------------------------------
 struct DgradArgs {
@@ -983,6 +1161,12 @@ P2PFL_API int p2pfl_conv2_prep(const float* w, long w_cs, void* wp, long wp_cs, 
     P2PFL_RETURN_LAST_ERROR();
 }
 
+// P2PFL_CONV2_DENSE=0: the window-row forward kernel for the exact-split policy too (A/B runs)
+static bool fwd_dense() {
+    static const bool on = [] { const char* e = getenv("P2PFL_CONV2_DENSE"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
 P2PFL_API int p2pfl_conv2_fwd(const float* a1, long a1_cs, const void* wp, long wp_cs, const float* bias,
                               long b_cs, float* a2, long a2_cs, uint8_t* code, long c_cs, int K, int B,
                               int CIN_, int COUT_, int KS, int prec, int flags, hipStream_t stream) {
@@ -997,6 +1181,8 @@ P2PFL_API int p2pfl_conv2_fwd(const float* a1, long a1_cs, const void* wp, long 
     dim3 grid(cdiv(K, 8) * 8 * (split ? B : cdiv(B, 2)));
     if (KS == 5 && !split) hipLaunchKernelGGL((conv2_fwd_kernel<5, 1>), grid, dim3(256), 0, stream, a);
     else if (KS == 3 && !split) hipLaunchKernelGGL((conv2_fwd_kernel<3, 1>), grid, dim3(256), 0, stream, a);
+    else if (KS == 5 && fwd_dense()) hipLaunchKernelGGL(conv2_fwd_dense_kernel<5>, grid, dim3(256), 0, stream, a);
+    else if (KS == 3 && fwd_dense()) hipLaunchKernelGGL(conv2_fwd_dense_kernel<3>, grid, dim3(256), 0, stream, a);
     else if (KS == 5) hipLaunchKernelGGL((conv2_fwd_kernel<5, SPLIT_TERMS>), grid, dim3(256), 0, stream, a);
     else if (KS == 3) hipLaunchKernelGGL((conv2_fwd_kernel<3, SPLIT_TERMS>), grid, dim3(256), 0, stream, a);
     else return -3;

@@ -716,6 +716,194 @@ __global__ __launch_bounds__(256, 2) void conv2_dgrad_split_kernel(DgradArgs a) 
     }
 }
 
+// Data gradient, exact-split policy, without the phantom row tile: 196 pixels are six full 32-row tiles and four pixels.
+// The kernel above issues 8 tiles (two per wave) for them. Here the twelve (tile, channel half of the pass) units are
+// dealt three to a wave - wave w reduces channels 16 (w & 1) .. + 15 of the pass over tiles 3 (w >> 1) + {0, 1, 2}, the
+// two waves of a tile triple add their accumulators through LDS at the end (fixed order) - and the four left-over pixels
+// run on v_mfma_f32_16x16x32_bf16 (all 32 channels of the pass per instruction, one 16-column tile per wave: waves 0 / 1
+// in the first pass, 2 / 3 in the second, summed at the end). Matrix-pipe time per tap, pass and wave: 18 x 32 (+ 6 x 16)
+// cycles against 24 x 32.
+template <int KS>
+__global__ __launch_bounds__(256, 2) void conv2_dgrad_dense_kernel(DgradArgs a) {
+    using G = Geo<KS>;
+    constexpr int NS = 3;
+    constexpr int WRS = 80;                     // LDS row of the weight slice: 32 n bf16 + 16 B pad
+    constexpr int IMG = G::XSS, WSL = CIN * WRS;
+    constexpr int PLANE = 2 * G::T * COUT * CIN;
+    __shared__ __attribute__((aligned(16))) unsigned char gimg[NS * IMG];
+    __shared__ __attribute__((aligned(16))) unsigned char wbuf[2][NS * WSL];
+
+    int c, b;
+    if (!xcd_map(a.B, a.K, c, b)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    const __bf16* wd = a.wp + c * a.wp_cs + G::T * COUT * CIN;
+    const float* gsrc = a.g + c * a.g_cs + (size_t)b * COUT * CELLS2;
+    const uint8_t* csrc = a.code + c * a.c_cs + (size_t)b * COUT * CELLS2;
+
+    constexpr int WPIECES = NS * 128, WROUNDS = (WPIECES + 255) / 256;
+    auto wload = [&](int t, int pass, bf16x8 (&w)[WROUNDS]) {
+#pragma unroll
+        for (int u = 0; u < WROUNDS; ++u) {
+            const int q = tid + 256 * u;
+            if (q < WPIECES) {
+                const int e = q >> 7, rem = q & 127;
+                w[u] = *reinterpret_cast<const bf16x8*>(wd + e * PLANE + t * COUT * CIN + (rem >> 2) * COUT + pass * 32 +
+                                                        (rem & 3) * 8);
+            }
+        }
+    };
+    auto wstore = [&](int buf, const bf16x8 (&w)[WROUNDS]) {
+#pragma unroll
+        for (int u = 0; u < WROUNDS; ++u) {
+            const int q = tid + 256 * u;
+            if (q < WPIECES) {
+                const int e = q >> 7, rem = q & 127;
+                *reinterpret_cast<bf16x8*>(wbuf[buf] + e * WSL + (rem >> 2) * WRS + (rem & 3) * 16) = w[u];
+            }
+        }
+    };
+
+    const int ksw = wave & 1, t0 = 3 * (wave >> 1);
+    int abase[3], pl[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int p = (t0 + i) * 32 + r;
+        pl[i] = p + 4 * h + 8 * ksw;             // (rotation of the pixel read for a tap: ((p + tap) >> 2) + h + 2 ks)
+        abase[i] = (p / P1) * G::XRS + (p % P1) * 64;
+    }
+    // left-over pixels 192..195 (row 13, x = 10..13) on the 16-row instruction: lane -> row = lane & 15 (pixel 192 +
+    // (lane & 3), rows >= 4 repeat it), channel chunk lane >> 4; B: input channel 16 (wave & 1) + (lane & 15)
+    const int lp = 192 + (lane & 3), lg = lane >> 4;
+    const int lbase = (lp / P1) * G::XRS + (lp % P1) * 64;
+    f32x16 acc[3];
+    f32x4 accl = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) __syncthreads();                 // all reads of the previous pass's images and slices are done
+        for (int i = tid; i < NS * IMG / 16; i += 256)
+            *reinterpret_cast<float4*>(gimg + i * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        {
+            bf16x8 w0[WROUNDS];
+            wload(0, pass, w0);
+            wstore(0, w0);
+        }
+        __syncthreads();
+        for (int task = tid; task < CELLS2 * 4; task += 256) {
+            const int cg = task / CELLS2, cell = task % CELLS2;
+            float gv[8]; int qc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                gv[i] = gsrc[(pass * 32 + cg * 8 + i) * CELLS2 + cell];
+                qc[i] = csrc[(pass * 32 + cg * 8 + i) * CELLS2 + cell];
+            }
+            bf16x8 tv[NS];
+            split_bf16x8<NS>(gv, tv);
+            const int Y = 2 * (cell / P2) + G::PAD, X = 2 * (cell % P2) + G::PAD;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int e = 0; e < NS; ++e) {
+                    bf16x8 v;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = (qc[i] == q) ? tv[e][i] : (__bf16)0.f;
+                    const int Yq = Y + (q >> 1), Xq = X + (q & 1);
+                    *reinterpret_cast<bf16x8*>(gimg + e * IMG + Yq * G::XRS + Xq * 64 +
+                                               ((cg + ((P1 * Yq + Xq) >> 2)) & 3) * 16) = v;
+                }
+            }
+        }
+        __syncthreads();
+        const bool left = (wave >> 1) == pass;     // (wave-uniform) this wave owns the left-over pixels in this pass
+
+        int ky = 0, kx = 0;   // mirrored tap index: image offset (ky,kx), weights of tap (KS-1-ky, KS-1-kx)
+#pragma unroll 1
+        for (int t = 0; t < G::T; ++t) {
+            bf16x8 wnext[WROUNDS];
+            if (t + 1 < G::T) wload(t + 1, pass, wnext);
+            const unsigned char* wb = wbuf[t & 1] + r * WRS + h * 16 + ksw * 32;
+            const int toff = ky * G::XRS + kx * 64, tapl = P1 * ky + kx;
+            bf16x8 bfr[NS];
+#pragma unroll
+            for (int e = 0; e < NS; ++e) bfr[e] = *reinterpret_cast<const bf16x8*>(wb + e * WSL);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int off = abase[i] + toff + (((pl[i] + tapl) >> 2) & 3) * 16;
+                bf16x8 af[NS];
+#pragma unroll
+                for (int e = 0; e < NS; ++e) af[e] = *reinterpret_cast<const bf16x8*>(gimg + e * IMG + off);
+#pragma unroll
+                for (int ea = 0; ea < NS; ++ea)
+#pragma unroll
+                    for (int eb = 0; eb < NS - ea; ++eb)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ea], bfr[eb], acc[i], 0, 0, 0);
+            }
+            if (left) {
+                const int off = lbase + toff + ((((lp + tapl) >> 2) + lg) & 3) * 16;
+                const unsigned char* wl = wbuf[t & 1] + (16 * ksw + (lane & 15)) * WRS + lg * 16;
+                bf16x8 af[NS], bl[NS];
+#pragma unroll
+                for (int e = 0; e < NS; ++e) {
+                    af[e] = *reinterpret_cast<const bf16x8*>(gimg + e * IMG + off);
+                    bl[e] = *reinterpret_cast<const bf16x8*>(wl + e * WSL);
+                }
+#pragma unroll
+                for (int ea = 0; ea < NS; ++ea)
+#pragma unroll
+                    for (int eb = 0; eb < NS - ea; ++eb)
+                        accl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ea], bl[eb], accl, 0, 0, 0);
+            }
+            if (t + 1 < G::T) wstore((t + 1) & 1, wnext);
+            __syncthreads();
+            if (++kx == KS) { kx = 0; ++ky; }
+        }
+    }
+
+    // ---- the odd waves hand their halves over (the loop's last barrier freed the images)
+    float* red = reinterpret_cast<float*>(gimg);          // [2 pairs][3 tiles][16][64] + left-over [4 waves][4][64]
+    float* redl = red + 2 * 3 * 16 * 64;
+    static_assert(NS * IMG >= (2 * 3 * 16 * 64 + 4 * 4 * 64) * 4, "the exchange must fit into the image buffer");
+    if (ksw) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[(((wave >> 1) * 3 + i) * 16 + e) * 64 + lane] = acc[i][e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) redl[(wave * 4 + e) * 64 + lane] = accl[e];
+    __syncthreads();
+    if (!ksw) {     // lane = input channel, registers 4g..4g+3 = four consecutive pixels -> float4
+        float* dst = a.da1 + c * a.da1_cs + ((size_t)b * CIN + r) * CELLS1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int p = (t0 + i) * 32 + 8 * g + 4 * h;
+                const float* o = red + (((wave >> 1) * 3 + i) * 16 + 4 * g) * 64 + lane;
+                *reinterpret_cast<float4*>(dst + p) = make_float4(acc[i][4 * g] + o[0], acc[i][4 * g + 1] + o[64],
+                                                                  acc[i][4 * g + 2] + o[128], acc[i][4 * g + 3] + o[192]);
+            }
+    } else if (wave == 1 || wave == 3) {
+        // left-over pixels: 16 x 16 accumulators (lane & 15 = input channel of the wave's column tile, lanes 0..15 hold rows
+        // 0..3 = pixels 192..195): wave 1 finishes column tile 0 (waves 0 + 2), wave 3 column tile 1 (waves 1 + 3)
+        if (lane < 16) {
+            const int j = wave >> 1;
+            const int ci = 16 * j + lane;
+            const float* p0 = redl + (j * 4) * 64 + lane;              // wave j     (first pass)
+            const float* p1 = redl + ((2 + j) * 4) * 64 + lane;        // wave 2 + j (second pass)
+            float* dst = a.da1 + c * a.da1_cs + ((size_t)b * CIN + ci) * CELLS1 + 192;
+            *reinterpret_cast<float4*>(dst) = make_float4(p0[0] + p1[0], p0[64] + p1[64], p0[128] + p1[128], p0[192] + p1[192]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // weight gradient:  dW[n][c][t] = sum_{b,p} G[b][p][n] * X[b][p + t][c],   db[n] = sum G[b][p][n]
 //
@@ -1167,6 +1355,12 @@ static bool fwd_dense() {
     return on;
 }
 
+// P2PFL_CONV2_DENSE_DGRAD=0: the 8-tile data-gradient kernel for the exact-split policy (A/B runs)
+static bool dgrad_dense() {
+    static const bool on = [] { const char* e = getenv("P2PFL_CONV2_DENSE_DGRAD"); return fwd_dense() && !(e && atoi(e) == 0); }();
+    return on;
+}
+
 P2PFL_API int p2pfl_conv2_fwd(const float* a1, long a1_cs, const void* wp, long wp_cs, const float* bias,
                               long b_cs, float* a2, long a2_cs, uint8_t* code, long c_cs, int K, int B,
                               int CIN_, int COUT_, int KS, int prec, int flags, hipStream_t stream) {
@@ -1202,6 +1396,8 @@ P2PFL_API int p2pfl_conv2_dgrad(const float* g, long g_cs, const uint8_t* code, 
     dim3 grid(cdiv(K, 8) * 8 * B);
     if (KS == 5 && !split) hipLaunchKernelGGL(conv2_dgrad_kernel<5>, grid, dim3(256), 0, stream, a);
     else if (KS == 3 && !split) hipLaunchKernelGGL(conv2_dgrad_kernel<3>, grid, dim3(256), 0, stream, a);
+    else if (KS == 5 && dgrad_dense()) hipLaunchKernelGGL(conv2_dgrad_dense_kernel<5>, grid, dim3(256), 0, stream, a);
+    else if (KS == 3 && dgrad_dense()) hipLaunchKernelGGL(conv2_dgrad_dense_kernel<3>, grid, dim3(256), 0, stream, a);
     else if (KS == 5) hipLaunchKernelGGL((conv2_dgrad_split_kernel<5, SPLIT_TERMS>), grid, dim3(256), 0, stream, a);
     else if (KS == 3) hipLaunchKernelGGL((conv2_dgrad_split_kernel<3, SPLIT_TERMS>), grid, dim3(256), 0, stream, a);
     else return -3;

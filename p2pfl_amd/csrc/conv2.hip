@@ -114,6 +114,7 @@ struct FwdArgs {
     float* a2;         long a2_cs;     // [K][B][64][49]
     uint8_t* code;     long c_cs;
     int K, B;
+    int ipb;                           // images per block of conv2_fwd_dense_kernel (0 = 1)
 };
 
 // NS = bf16 terms per operand (1: bf16 mode; 3: exact fp32 split, six MFMAs per fragment pair - PREC_F32_SPLIT).
@@ -302,40 +303,57 @@ __global__ __launch_bounds__(256, 2) void conv2_fwd_dense_kernel(FwdArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char ximg[NS * IMG];
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[NS * WSL];
 
-    int c, b0;
-    if (!xcd_map(a.B, a.K, c, b0)) return;
+    const int ipb = a.ipb > 0 ? a.ipb : 1;
+    int c, sub;
+    if (!xcd_map(cdiv(a.B, ipb), a.K, c, sub)) return;
+    const int b_begin = sub * ipb, b_end = min(a.B, b_begin + ipb);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
 
-    // ---- stage the padded image (fp32 NCHW -> bf16 terms, channel-last, rotated chunks)
+    // ---- staging of one sample in two halves: global loads into registers (issued BEFORE the previous sample's tap loop,
+    // so they fly under its MFMAs), then split + LDS stores (fp32 NCHW -> bf16 terms, channel-last, rotated chunks)
     const float* a1 = a.a1 + c * a.a1_cs;
-    for (int task = tid; task < G::IW * G::IW * 4; task += 256) {
-        const int g = task & 3, rr = task >> 2;
-        const int Y = rr / G::IW, X = rr % G::IW;
-        const int y = Y - G::PAD, x = X - G::PAD;
-        float v[8];
+    const __bf16* wf = a.wp + c * a.wp_cs;
+    constexpr int NTASK = G::IW * G::IW * 4, NIT = (NTASK + 255) / 256;
+    float sv[NIT][8];
+    bf16x8 w0[NS];
+    auto prefetch = [&](int b) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = 0.f;
-        if (y >= 0 && y < P1 && x >= 0 && x < P1) {
-            const float* src = a1 + ((size_t)b0 * CIN + 8 * g) * CELLS1 + y * P1 + x;
+        for (int u = 0; u < NIT; ++u) {
+            const int task = tid + 256 * u;
+            const int g = task & 3, rr = task >> 2;
+            const int y = rr / G::IW - G::PAD, x = rr % G::IW - G::PAD;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = src[i * CELLS1];
+            for (int i = 0; i < 8; ++i) sv[u][i] = 0.f;
+            if (task < NTASK && y >= 0 && y < P1 && x >= 0 && x < P1) {
+                const float* src = a1 + ((size_t)b * CIN + 8 * g) * CELLS1 + y * P1 + x;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sv[u][i] = src[i * CELLS1];
+            }
         }
-        bf16x8 tv[NS];
-        split_bf16x8<NS>(v, tv);
-        const int pos = (g + (X >> 1) + 3 * (Y >> 1)) & 3;
+#pragma unroll
+        for (int e = 0; e < NS; ++e) w0[e] = *reinterpret_cast<const bf16x8*>(wf + e * PLANE + tid * 8);
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int task = tid + 256 * u;
+            if (task < NTASK) {
+                const int g = task & 3, rr = task >> 2;
+                const int Y = rr / G::IW, X = rr % G::IW;
+                bf16x8 tv[NS];
+                split_bf16x8<NS>(sv[u], tv);
+                const int pos = (g + (X >> 1) + 3 * (Y >> 1)) & 3;
+#pragma unroll
+                for (int e = 0; e < NS; ++e)
+                    *reinterpret_cast<bf16x8*>(ximg + e * IMG + Y * G::XRS + X * 64 + pos * 16) = tv[e];
+            }
+        }
 #pragma unroll
         for (int e = 0; e < NS; ++e)
-            *reinterpret_cast<bf16x8*>(ximg + e * IMG + Y * G::XRS + X * 64 + pos * 16) = tv[e];
-    }
-    const __bf16* wf = a.wp + c * a.wp_cs;
-#pragma unroll
-    for (int e = 0; e < NS; ++e) {
-        const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wf + e * PLANE + tid * 8);
-        *reinterpret_cast<bf16x8*>(wbuf + e * WSL + (tid >> 2) * 80 + (tid & 3) * 16) = w0;
-    }
-    __syncthreads();
+            *reinterpret_cast<bf16x8*>(wbuf + e * WSL + (tid >> 2) * 80 + (tid & 3) * 16) = w0[e];
+    };
 
     // ---- my units: column half jc, row tiles 3 (wave >> 1) + {0, 1, 2}; my pixel of each tile (padded coordinates of
     // tap (0, 0)): window 8 tile + (r >> 2), corner q = r & 3
@@ -353,107 +371,115 @@ __global__ __launch_bounds__(256, 2) void conv2_fwd_dense_kernel(FwdArgs a) {
     const int lq = lane & 3, lg = lane >> 4;
     const int lpy = 12 + (lq >> 1), lpx = 12 + (lq & 1);
     const int lbase = lpy * G::XRS + lpx * 64;
-    f32x16 acc[3];
-    f32x4 accl = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-
-    int ky = 0, kx = 0;
+    prefetch(b_begin);
 #pragma unroll 1
-    for (int t = 0; t < G::T; ++t) {
-        bf16x8 wnext[NS];
-        if (t + 1 < G::T) {
-#pragma unroll
-            for (int e = 0; e < NS; ++e)
-                wnext[e] = *reinterpret_cast<const bf16x8*>(wf + e * PLANE + (t + 1) * COUT * CIN + tid * 8);
-        }
-        const unsigned char* wb = wbuf + (32 * jc + r) * 80 + h * 16;
-        const int tap_off = ky * G::XRS + kx * 64;
-        int rot[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) rot[i] = ((px[i] + kx) >> 1) + 3 * ((py[i] + ky) >> 1) + h;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 bf[NS];
-#pragma unroll
-            for (int e = 0; e < NS; ++e) bf[e] = *reinterpret_cast<const bf16x8*>(wb + e * WSL + ks * 32);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int off = abase[i] + tap_off + ((rot[i] + 2 * ks) & 3) * 16;
-                bf16x8 af[NS];
-#pragma unroll
-                for (int e = 0; e < NS; ++e) af[e] = *reinterpret_cast<const bf16x8*>(ximg + e * IMG + off);
-#pragma unroll
+    for (int b = b_begin; b < b_end; ++b) {
+        commit();
+        __syncthreads();
+        if (b + 1 < b_end) prefetch(b + 1);
+        f32x16 acc[3];
+        f32x4 accl = {0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+        for (int i = 0; i < 3; ++i)
+    #pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+        int ky = 0, kx = 0;
+    #pragma unroll 1
+        for (int t = 0; t < G::T; ++t) {
+            bf16x8 wnext[NS];
+            if (t + 1 < G::T) {
+    #pragma unroll
+                for (int e = 0; e < NS; ++e)
+                    wnext[e] = *reinterpret_cast<const bf16x8*>(wf + e * PLANE + (t + 1) * COUT * CIN + tid * 8);
+            }
+            const unsigned char* wb = wbuf + (32 * jc + r) * 80 + h * 16;
+            const int tap_off = ky * G::XRS + kx * 64;
+            int rot[3];
+    #pragma unroll
+            for (int i = 0; i < 3; ++i) rot[i] = ((px[i] + kx) >> 1) + 3 * ((py[i] + ky) >> 1) + h;
+    #pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 bf[NS];
+    #pragma unroll
+                for (int e = 0; e < NS; ++e) bf[e] = *reinterpret_cast<const bf16x8*>(wb + e * WSL + ks * 32);
+    #pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int off = abase[i] + tap_off + ((rot[i] + 2 * ks) & 3) * 16;
+                    bf16x8 af[NS];
+    #pragma unroll
+                    for (int e = 0; e < NS; ++e) af[e] = *reinterpret_cast<const bf16x8*>(ximg + e * IMG + off);
+    #pragma unroll
+                    for (int ea = 0; ea < NS; ++ea)
+    #pragma unroll
+                        for (int eb = 0; eb < NS - ea; ++eb)
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ea], bf[eb], acc[i], 0, 0, 0);
+                }
+            }
+            {   // left-over window: all 32 channels in one instruction, 16 columns per wave
+                const int lrot = ((lpx + kx) >> 1) + 3 * ((lpy + ky) >> 1) + lg;
+                const int off = lbase + tap_off + (lrot & 3) * 16;
+                const unsigned char* wl = wbuf + (16 * wave + (lane & 15)) * 80 + lg * 16;
+                bf16x8 af[NS], bl[NS];
+    #pragma unroll
+                for (int e = 0; e < NS; ++e) {
+                    af[e] = *reinterpret_cast<const bf16x8*>(ximg + e * IMG + off);
+                    bl[e] = *reinterpret_cast<const bf16x8*>(wl + e * WSL);
+                }
+    #pragma unroll
                 for (int ea = 0; ea < NS; ++ea)
-#pragma unroll
+    #pragma unroll
                     for (int eb = 0; eb < NS - ea; ++eb)
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ea], bf[eb], acc[i], 0, 0, 0);
+                        accl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ea], bl[eb], accl, 0, 0, 0);
             }
-        }
-        {   // left-over window: all 32 channels in one instruction, 16 columns per wave
-            const int lrot = ((lpx + kx) >> 1) + 3 * ((lpy + ky) >> 1) + lg;
-            const int off = lbase + tap_off + (lrot & 3) * 16;
-            const unsigned char* wl = wbuf + (16 * wave + (lane & 15)) * 80 + lg * 16;
-            bf16x8 af[NS], bl[NS];
-#pragma unroll
-            for (int e = 0; e < NS; ++e) {
-                af[e] = *reinterpret_cast<const bf16x8*>(ximg + e * IMG + off);
-                bl[e] = *reinterpret_cast<const bf16x8*>(wl + e * WSL);
+            __syncthreads();                                 // every wave finished reading the single slice
+            if (t + 1 < G::T) {
+    #pragma unroll
+                for (int e = 0; e < NS; ++e)
+                    *reinterpret_cast<bf16x8*>(wbuf + e * WSL + (tid >> 2) * 80 + (tid & 3) * 16) = wnext[e];
             }
-#pragma unroll
-            for (int ea = 0; ea < NS; ++ea)
-#pragma unroll
-                for (int eb = 0; eb < NS - ea; ++eb)
-                    accl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ea], bl[eb], accl, 0, 0, 0);
+            __syncthreads();
+            if (++kx == KS) { kx = 0; ++ky; }
         }
-        __syncthreads();                                 // every wave finished reading the single slice
-        if (t + 1 < G::T) {
-#pragma unroll
-            for (int e = 0; e < NS; ++e)
-                *reinterpret_cast<bf16x8*>(wbuf + e * WSL + (tid >> 2) * 80 + (tid & 3) * 16) = wnext[e];
+
+        // ---- epilogue: bias + ReLU + 2x2 max-pool + arg-max code from the accumulators, assembled in the idle image buffer
+        // ([64][49] floats + codes = the sample's contiguous piece of a2 / code) and written as 16-byte pieces
+        static_assert(NS * IMG >= COUT * CELLS2 * 5, "output staging must fit into the image buffer");
+        float* out_s = reinterpret_cast<float*>(ximg);
+        uint8_t* code_s = ximg + COUT * CELLS2 * 4;
+        const float* bias = a.bias + c * a.b_cs;
+        auto pool = [&](float v0, float v1, float v2, float v3, float bv, int n, int W) {
+            float best = v0; int q = 0;
+            if (v1 > best) { best = v1; q = 1; }
+            if (v2 > best) { best = v2; q = 2; }
+            if (v3 > best) { best = v3; q = 3; }
+            best += bv;
+            if (!(best > 0.f)) { best = 0.f; q = 4; }
+            out_s[n * CELLS2 + W] = best;
+            code_s[n * CELLS2 + W] = (uint8_t)q;
+        };
+        {
+            const int n = 32 * jc + r;
+            const float bv = bias[n];
+    #pragma unroll
+            for (int i = 0; i < 3; ++i)
+    #pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    pool(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3], bv, n, 8 * (t0 + i) + 2 * g + h);
+        }
+        if (lane < 16) {     // 16 x 16 accumulator: lane = column, rows 4 (lane >> 4) + reg -> lanes 0..15 hold window 48
+            const int n = 16 * wave + lane;
+            pool(accl[0], accl[1], accl[2], accl[3], bias[n], n, CELLS2 - 1);
         }
         __syncthreads();
-        if (++kx == KS) { kx = 0; ++ky; }
+        float* a2 = a.a2 + c * a.a2_cs + (size_t)b * COUT * CELLS2;
+        uint8_t* code = a.code + c * a.c_cs + (size_t)b * COUT * CELLS2;
+        for (int i = tid; i < COUT * CELLS2 / 4; i += 256)
+            reinterpret_cast<f32x4*>(a2)[i] = reinterpret_cast<const f32x4*>(out_s)[i];
+        for (int i = tid; i < COUT * CELLS2 / 16; i += 256)
+            reinterpret_cast<f32x4*>(code)[i] = reinterpret_cast<const f32x4*>(code_s)[i];
+        __syncthreads();               // the output staging is read: the image buffer may take the next sample
     }
-
-    // ---- epilogue: bias + ReLU + 2x2 max-pool + arg-max code from the accumulators, assembled in the idle image buffer
-    // ([64][49] floats + codes = the sample's contiguous piece of a2 / code) and written as 16-byte pieces
-    static_assert(NS * IMG >= COUT * CELLS2 * 5, "output staging must fit into the image buffer");
-    float* out_s = reinterpret_cast<float*>(ximg);
-    uint8_t* code_s = ximg + COUT * CELLS2 * 4;
-    const float* bias = a.bias + c * a.b_cs;
-    auto pool = [&](float v0, float v1, float v2, float v3, float bv, int n, int W) {
-        float best = v0; int q = 0;
-        if (v1 > best) { best = v1; q = 1; }
-        if (v2 > best) { best = v2; q = 2; }
-        if (v3 > best) { best = v3; q = 3; }
-        best += bv;
-        if (!(best > 0.f)) { best = 0.f; q = 4; }
-        out_s[n * CELLS2 + W] = best;
-        code_s[n * CELLS2 + W] = (uint8_t)q;
-    };
-    {
-        const int n = 32 * jc + r;
-        const float bv = bias[n];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                pool(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3], bv, n, 8 * (t0 + i) + 2 * g + h);
-    }
-    if (lane < 16) {     // 16 x 16 accumulator: lane = column, rows 4 (lane >> 4) + reg -> lanes 0..15 hold window 48
-        const int n = 16 * wave + lane;
-        pool(accl[0], accl[1], accl[2], accl[3], bias[n], n, CELLS2 - 1);
-    }
-    __syncthreads();
-    float* a2 = a.a2 + c * a.a2_cs + (size_t)b0 * COUT * CELLS2;
-    uint8_t* code = a.code + c * a.c_cs + (size_t)b0 * COUT * CELLS2;
-    for (int i = tid; i < COUT * CELLS2 / 4; i += 256)
-        reinterpret_cast<f32x4*>(a2)[i] = reinterpret_cast<const f32x4*>(out_s)[i];
-    for (int i = tid; i < COUT * CELLS2 / 16; i += 256)
-        reinterpret_cast<f32x4*>(code)[i] = reinterpret_cast<const f32x4*>(code_s)[i];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1361,6 +1387,17 @@ static bool dgrad_dense() {
     return on;
 }
 
+// samples a block of the dense forward walks through (the next sample's global loads fly under the tap loop of the
+// current one); P2PFL_CONV2_IPB forces a count. ONE is best everywhere (tools/probe/c2_ipb.sh; 1 / 2 / 4 / 8 samples per
+// block: 1000 clients 3x3 1268 / 1295 / 1301 / 1337 us, 50 clients 5x5 179 / 206 / 207 / 253, 10 clients 55 / 68 / 121 / 232):
+// the kernel does not wait for its global loads - per tap its eight waves read 240 KB of fragments from LDS, 1920 cycles of
+// the LDS pipe against 2496 of the matrix pipe - and more, shorter blocks balance better.
+static int fwd_images_per_block(int K, int B) {
+    static const int forced = [] { const char* e = getenv("P2PFL_CONV2_IPB"); return e ? atoi(e) : 0; }();
+    if (forced > 0) return forced > B ? B : forced;
+    return 1;
+}
+
 P2PFL_API int p2pfl_conv2_fwd(const float* a1, long a1_cs, const void* wp, long wp_cs, const float* bias,
                               long b_cs, float* a2, long a2_cs, uint8_t* code, long c_cs, int K, int B,
                               int CIN_, int COUT_, int KS, int prec, int flags, hipStream_t stream) {
@@ -1371,8 +1408,12 @@ P2PFL_API int p2pfl_conv2_fwd(const float* a1, long a1_cs, const void* wp, long 
     const bool split = prec == PREC_F32_SPLIT;
     if ((wp_cs & 7) || ((uintptr_t)wp & 15) || wp_cs < 2L * (split ? SPLIT_TERMS : 1) * KS * KS * COUT * CIN) return -2;
     if (((uintptr_t)a2 & 15) || (a2_cs & 3) || ((uintptr_t)code & 15) || (c_cs & 15)) return -2;   // 16-byte block stores
-    FwdArgs a{a1, a1_cs, (const __bf16*)wp, wp_cs, bias, b_cs, a2, a2_cs, code, c_cs, K, B};
+    FwdArgs a{a1, a1_cs, (const __bf16*)wp, wp_cs, bias, b_cs, a2, a2_cs, code, c_cs, K, B, 1};
     dim3 grid(cdiv(K, 8) * 8 * (split ? B : cdiv(B, 2)));
+    if (split && fwd_dense()) {
+        a.ipb = fwd_images_per_block(K, B);
+        grid = dim3(cdiv(K, 8) * 8 * cdiv(B, a.ipb));
+    }
     if (KS == 5 && !split) hipLaunchKernelGGL((conv2_fwd_kernel<5, 1>), grid, dim3(256), 0, stream, a);
     else if (KS == 3 && !split) hipLaunchKernelGGL((conv2_fwd_kernel<3, 1>), grid, dim3(256), 0, stream, a);
     else if (KS == 5 && fwd_dense()) hipLaunchKernelGGL(conv2_fwd_dense_kernel<5>, grid, dim3(256), 0, stream, a);

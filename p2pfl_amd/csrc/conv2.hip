@@ -290,8 +290,11 @@ __global__ __launch_bounds__(256, 2) void conv2_fwd_kernel(FwdArgs a) {
 // per wave, all 32 input channels in one instruction). Matrix-pipe time per tap and wave: 36 x 32 + 6 x 16 = 1248
 // cycles against 48 x 32 = 1536.
 // LDS: the chunk rotation of a pixel is ((X >> 1) - (Y >> 1)) & 3 = (W + const) & 3 for the pixels that the four windows
-// of a 16-lane group read for one tap - four consecutive windows, four different rotations, whatever the window row - and
-// the four pixels of a window differ in the 64-byte slot: 16 different 16-byte slots per group, as before.
+// of a 16-lane group read for one tap - four consecutive windows, four different rotations, also across a window-row
+// wrap. Not conflict-free like the window-row layout: for taps with odd ky the two rows of a window fall into different
+// rotation classes (model: 1.33 - 1.4 LDS cycles per fragment read, no rotation that is linear in the pixel position does
+// better; SQ_LDS_BANK_CONFLICT 30 % of the LDS cycles against 16 %, profiles/r3_final_pmc_summary.csv). The kernel trades
+// those cycles for a fifth of the matrix-pipe time and comes out 10 % ahead.
 // ---------------------------------------------------------------------------------------
 template <int KS>
 __global__ __launch_bounds__(256, 2) void conv2_fwd_dense_kernel(FwdArgs a) {

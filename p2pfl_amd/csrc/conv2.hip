@@ -1322,6 +1322,197 @@ __global__ __launch_bounds__(512, 1) void conv2_wgrad_split_kernel(WgradArgs a) 
     }
 }
 
+// The same with ALL 64 gradient channels in one block (X terms 3 x 21 KB + G terms 3 x 26 KB = 146 KB): the input image
+// is staged once per (client, sample) instead of once per row tile, a launch has K x NS blocks instead of 2 K x NS
+// (50 clients: 5 batch splits = 250 blocks on 256 CUs; the two-tile form has 200 or 400), and the 2 x T (row tile, tap)
+// units are dealt to the 8 waves as 7/6/6/6 + 6/7/6/6 (5x5; 3x3: 3/2/2/2 + 2/3/2/2) - waves w and w + 4 share a SIMD, so
+// every SIMD carries 13 / 13 / 12 / 12 units and the two bias units ride on the light ones.
+template <int KS>
+__global__ __launch_bounds__(512, 1) void conv2_wgrad_split64_kernel(WgradArgs a) {
+    constexpr int NS = 3;
+    using G = Geo<KS>;
+    constexpr int T = G::T;
+    constexpr int NTAP = (T + 3) / 4;                    // most taps per wave (T % 4 == 1: one wave of a row tile has it)
+    static_assert(T % 4 == 1, "tap split assumes 25 or 9 taps");
+    constexpr int XRS = G::IW * 64 + ((((P1 - G::IW) * 64) % 256) + 256) % 256;
+    constexpr int XROWS = G::IW + 1;                     // +1 zero row: K padding (pixels 196..207) reads it
+    constexpr int GPS = 128;                             // all 64 gradient channels
+    constexpr int KSTEPS = (CELLS1 + 15) / 16;           // 13
+    constexpr int NPIX = KSTEPS * 16;                    // 208 (last 12 stay zero)
+    constexpr int XIMG = XROWS * XRS, GIMG = NPIX * GPS;
+    __shared__ __attribute__((aligned(16))) unsigned char ximg[NS * XIMG];
+    __shared__ __attribute__((aligned(16))) unsigned char gimg[NS * GIMG];
+
+    int c, split;
+    if (!xcd_map(a.NS, a.K, c, split)) return;
+    const int b_begin = split * a.B / a.NS, b_end = (split + 1) * a.B / a.NS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = wv >> 2;                              // row tile (32 gradient channels) of this wave
+    const int jj = ((wv & 3) - mt) & 3;                  // its tap group, rotated by the row tile (SIMD balance)
+    const int t_begin = jj * (T / 4) + (jj > 0 ? 1 : 0);
+    const int ntap = T / 4 + (jj == 0 ? 1 : 0);         // NTAP or NTAP - 1
+    const bool do_bias = jj == 2;                        // wave-uniform; a light wave on SIMD 2 (mt 0) / 3 (mt 1)
+    int toff[NTAP];
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j) {
+        const int t = min(t_begin + j, T - 1);
+        toff[j] = (t / KS) * XRS + (t % KS) * 64;
+    }
+
+    for (int i = tid; i < NS * XIMG / 16; i += 512)
+        *reinterpret_cast<float4*>(ximg + i * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < NS * GIMG / 16; i += 512)
+        *reinterpret_cast<float4*>(gimg + i * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // lane roles in the transposed reads
+    const int grp = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+    const int p_lane = (grp >> 1) * 8 + q;                          // pixel of this lane within a k-step (+4h)
+    const int ch_off = ((grp & 1) * 16 + 4 * pq) * 2;                // byte offset of its 4 channels (X; G: + 64 mt)
+
+    // staging roles (global -> registers -> LDS)
+    float xv[2][8]; float gv[8]; int qc[8];
+    auto prefetch = [&](int b) {
+        const float* a1 = a.a1 + c * a.a1_cs + (size_t)b * CIN * CELLS1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int task = tid + 512 * u;
+            if (task < CELLS1 * 4) {
+                const float* src = a1 + (task & 3) * 8 * CELLS1 + (task >> 2);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xv[u][i] = src[i * CELLS1];
+            }
+        }
+        if (tid < CELLS2 * 8) {
+            const int cg = tid / CELLS2, cell = tid % CELLS2;
+            const float* gs = a.g + c * a.g_cs + ((size_t)b * COUT + cg * 8) * CELLS2 + cell;
+            const uint8_t* cs = a.code + c * a.c_cs + ((size_t)b * COUT + cg * 8) * CELLS2 + cell;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { gv[i] = gs[i * CELLS2]; qc[i] = cs[i * CELLS2]; }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int task = tid + 512 * u;
+            if (task < CELLS1 * 4) {
+                const int p = task >> 2;
+                bf16x8 tv[NS];
+                split_bf16x8<NS>(xv[u], tv);
+#pragma unroll
+                for (int e = 0; e < NS; ++e)
+                    *reinterpret_cast<bf16x8*>(ximg + e * XIMG + (p / P1 + G::PAD) * XRS + (p % P1 + G::PAD) * 64 +
+                                               (task & 3) * 16) = tv[e];
+            }
+        }
+        if (tid < CELLS2 * 8) {
+            const int cg = tid / CELLS2, cell = tid % CELLS2;
+            const int p00 = 2 * (cell / P2) * P1 + 2 * (cell % P2);
+            bf16x8 tv[NS];
+            split_bf16x8<NS>(gv, tv);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+#pragma unroll
+                for (int e = 0; e < NS; ++e) {
+                    bf16x8 v;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = (qc[i] == qq) ? tv[e][i] : (__bf16)0.f;
+                    *reinterpret_cast<bf16x8*>(gimg + e * GIMG + (p00 + (qq >> 1) * P1 + (qq & 1)) * GPS + cg * 16) = v;
+                }
+            }
+        }
+    };
+
+    f32x16 acc[NTAP], accb;
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accb[e] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+    // one sample's k loop with a compile-time tap count / bias flag
+    auto kloop = [&](auto nt_c, auto bias_c) {
+        constexpr int NT = decltype(nt_c)::value;
+        constexpr bool BIAS = decltype(bias_c)::value;
+#pragma unroll 1
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int pa = ks * 16 + p_lane, pb = pa + 4;
+            const unsigned char* ga = gimg + pa * GPS + mt * 64 + ch_off;
+            const unsigned char* xa = ximg + (pa / P1) * XRS + (pa % P1) * 64 + ch_off;
+            const unsigned char* xb = ximg + (pb / P1) * XRS + (pb % P1) * 64 + ch_off;
+            bf16x8 af[NS];
+#pragma unroll
+            for (int e = 0; e < NS; ++e) af[e] = tr_frag(ga + e * GIMG, ga + e * GIMG + 4 * GPS);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                bf16x8 bfr[NS];
+#pragma unroll
+                for (int e = 0; e < NS; ++e) bfr[e] = tr_frag(xa + e * XIMG + toff[j], xb + e * XIMG + toff[j]);
+#pragma unroll
+                for (int ea = 0; ea < NS; ++ea)
+#pragma unroll
+                    for (int eb = 0; eb < NS - ea; ++eb)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ea], bfr[eb], acc[j], 0, 0, 0);
+            }
+            if (BIAS) {
+#pragma unroll
+                for (int e = 0; e < NS; ++e) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[e], ones, accb, 0, 0, 0);
+            }
+        }
+    };
+    using std::integral_constant;
+
+    if (b_begin < b_end) prefetch(b_begin);
+    for (int item = b_begin; item < b_end; ++item) {
+        __syncthreads();            // everyone finished reading the previous images (or zero-filling)
+        commit();
+        __syncthreads();
+        if (item + 1 < b_end) prefetch(item + 1);
+        if (do_bias) kloop(integral_constant<int, NTAP - 1>{}, integral_constant<bool, true>{});
+        else if (ntap == NTAP) kloop(integral_constant<int, NTAP>{}, integral_constant<bool, false>{});
+        else kloop(integral_constant<int, NTAP - 1>{}, integral_constant<bool, false>{});
+    }
+
+    const int ci = lane & 31;
+    if (a.part != nullptr) {
+        float* pw = a.part + ((size_t)c * a.NS + split) * (T * COUT * CIN + COUT);
+#pragma unroll
+        for (int j = 0; j < NTAP; ++j) {
+            if (j < ntap) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    pw[((t_begin + j) * COUT + mt * 32 + mfma_row_(e, lane)) * CIN + ci] = acc[j][e];
+            }
+        }
+        if (do_bias && ci == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) pw[T * COUT * CIN + mt * 32 + mfma_row_(e, lane)] = accb[e];
+        }
+        return;
+    }
+    float* dw = a.dw + c * a.dw_cs;
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j) {
+        if (j < ntap) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = mt * 32 + mfma_row_(e, lane);
+                dw[((size_t)n * CIN + ci) * T + t_begin + j] = acc[j][e];
+            }
+        }
+    }
+    if (do_bias && ci == 0) {
+        float* db = a.db + c * a.db_cs;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) db[mt * 32 + mfma_row_(e, lane)] = accb[e];
+    }
+}
+
 // Sum of the NS batch-split partials [t][n][ci] -> dW[n][ci][t], db[n]. One block per (client, n): reads
 // are 128-B runs, the transposition goes through LDS, the CIN*T floats of dW[n] leave as one contiguous run.
 template <int KS>
@@ -1489,15 +1680,36 @@ static void wgrad_split(int K, int B, int KS, int cus, int& np, int& ns) {
     }
 }
 
+// Which filter sizes take the 64-channel blocks of conv2_wgrad_split64_kernel: 3x3 (1000 clients 1741 -> 1421 us, 50 clients
+// 124 -> 112). The 5x5 instance needs 7 accumulator tiles per wave beside the staging registers and spills (50 clients:
+// 250 us against 225 for the two-row-tile form). P2PFL_WGRAD_WIDE=0 / 1: none / both (A/B runs).
+static bool wgrad_wide_for(int KS) {
+    static const int mode = [] { const char* e = getenv("P2PFL_WGRAD_WIDE"); return e ? atoi(e) : -1; }();
+    return mode < 0 ? KS == 3 : mode != 0;
+}
+
 // Batch splits of the split-operand weight gradient (one block per CU at a time, 2 * K * ns blocks): the count
 // <= 8 with the best (CU fill of the last round) x (evenness of the sample split). More splits must buy > 15 %:
 // partials cost a second kernel (measured, 100 clients x 32 samples: 1 split 0.426 ms, 5 splits 0.441 ms although
 // the blocks alone are 14 % better packed; 16 splits 0.548 ms). 100 clients -> 1; 1000 -> 1; 10 -> 8.
-static int wgrad_split_batches(int K, int B, int cus) {
+static int wgrad_split_batches(int K, int B, int cus, int KS) {
     static const int forced = [] { const char* e = getenv("P2PFL_WGRAD_NS"); return e ? atoi(e) : 0; }();
     if (forced > 0) return forced > B ? B : forced;
     int best = 1;
     double best_eff = 0.0;
+    if (wgrad_wide_for(KS)) {
+        // 64-channel blocks: K * ns of them, the blocks of a client on ONE XCD (xcd_map) - what has to come out even is the
+        // number of block rounds of the fullest XCD (50 clients: 7 on an XCD; 4 splits = 28 blocks on its 32 CUs 112 us,
+        // 5 splits = 35 blocks 161 us, 8 splits = 56 blocks 116 us; tools/probe/c2w_wide.sh)
+        const int per_xcd = cus / 8 > 0 ? cus / 8 : 1;
+        for (int ns = 1; ns <= 8 && ns <= B; ++ns) {
+            const int rounds = cdiv(cdiv(K, 8) * ns, per_xcd);
+            const double fill = (double)K * ns / (8.0 * rounds * per_xcd);
+            const double even = ((double)B / ns) / (double)cdiv(B, ns);
+            if (fill * even > best_eff * (best_eff > 0.0 ? 1.15 : 1.0) + 1e-9) { best_eff = fill * even; best = ns; }
+        }
+        return best;
+    }
     for (int ns = 1; ns <= 8 && ns <= B; ++ns) {
         const long blocks = 2L * K * ns;
         const double fill = (double)blocks / (double)(cdiv((int)blocks, cus) * (long)cus);
@@ -1512,7 +1724,7 @@ P2PFL_API long p2pfl_conv2_wgrad_scratch(int K, int B, int KS, int prec) {
     if (K <= 0 || B <= 0) return 0;
     if (prec == PREC_F32) return conv2_wgrad_f32_scratch(K, B, KS);
     int np, ns;
-    if (prec == PREC_F32_SPLIT) ns = wgrad_split_batches(K, B, num_cus());
+    if (prec == PREC_F32_SPLIT) ns = wgrad_split_batches(K, B, num_cus(), KS);
     else wgrad_split(K, B, KS, num_cus(), np, ns);
     return ns > 1 ? (long)K * ns * (KS * KS * COUT * CIN + COUT) : 0;
 }
@@ -1533,14 +1745,20 @@ P2PFL_API int p2pfl_conv2_wgrad_opt(const float* g, long g_cs, const uint8_t* co
     if (KS != 5 && KS != 3) return -3;
     const long pw = (long)KS * KS * COUT * CIN + COUT;
     if (prec == PREC_F32_SPLIT) {
-        int ns = wgrad_split_batches(K, B, num_cus());
+        int ns = wgrad_split_batches(K, B, num_cus(), KS);
         if (scratch == nullptr || scratch_floats < (long)K * ns * pw) ns = 1;
         if (fold && (scratch == nullptr || scratch_floats < (long)K * ns * pw)) return -5;
         WgradArgs a{g, g_cs, code, c_cs, a1, a1_cs, dw, dw_cs, db, db_cs, K, B, (ns > 1 || fold) ? scratch : nullptr, ns,
                     make_opt_epi(opt)};
+        if (wgrad_wide_for(KS)) {
+            const dim3 grid(cdiv(K, 8) * 8 * ns);
+            if (KS == 5) hipLaunchKernelGGL(conv2_wgrad_split64_kernel<5>, grid, dim3(512), 0, stream, a);
+            else hipLaunchKernelGGL(conv2_wgrad_split64_kernel<3>, grid, dim3(512), 0, stream, a);
+        } else {
         const dim3 grid(cdiv(K, 8) * 8 * 2 * ns);
         if (KS == 5) hipLaunchKernelGGL((conv2_wgrad_split_kernel<5, SPLIT_TERMS>), grid, dim3(512), 0, stream, a);
         else hipLaunchKernelGGL((conv2_wgrad_split_kernel<3, SPLIT_TERMS>), grid, dim3(512), 0, stream, a);
+        }
         if (a.part != nullptr) {
             if (KS == 5) hipLaunchKernelGGL(conv2_wgrad_reduce_kernel<5>, dim3(COUT, K), dim3(256), 0, stream, a);
             else hipLaunchKernelGGL(conv2_wgrad_reduce_kernel<3>, dim3(COUT, K), dim3(256), 0, stream, a);

@@ -45,7 +45,7 @@ template <int KS>
 __global__ __launch_bounds__(256) void conv1_fwd_f32_kernel(Conv1Args a) {
     constexpr int PAD = KS / 2;
     constexpr int NKK = (KS + 1) / 2;           // filter-row pairs: 3 / 4
-    constexpr int ROWS = IMG + 2 * NKK;         // last pixel row 27 + last tap row 2 NKK - 1
+    constexpr int ROWS = IMG + 2 * NKK;         // last pixel row 27 + last tap row KS - 1 (+ the phantom tap T of an odd T)
     constexpr int LW = 36;                      // last pixel column 27 + kx 6 = 33
     constexpr int NPX = IMG * IMG / 4;          // float4 per image
     constexpr int OT_LD = 40, CT_LD = 48;       // output patch rows: 32 windows + pad (bank spread / 16-B rows)
@@ -75,16 +75,16 @@ __global__ __launch_bounds__(256) void conv1_fwd_f32_kernel(Conv1Args a) {
             if (lane + 64 * i < NPX) px[i] = src[lane + 64 * i];
     }
     for (int i = lane; i < ROWS * LW; i += 64) my[i] = 0.f;   // zero border, once
-    // A operand: filter taps of filter r, row 2 kk + h
-    float wf[NKK][KS];
+    // A operand: the taps of filter r in PAIRS of consecutive taps (2 i, 2 i + 1) - lane half h holds tap 2 i + h - i.e.
+    // ceil(T / 2) = 13 / 25 MFMAs per accumulator; pairing filter ROWS (ky, ky + 1) costs 3 x 5 = 15 / 4 x 7 = 28 with a
+    // phantom row. The image offset of tap 2 i + 1 is that of tap 2 i plus 1, or plus LW - (KS - 1) where the pair wraps
+    // to the next filter row: two per-lane base pointers, every read stays base + immediate.
+    constexpr int T = KS * KS, NPAIR = (T + 1) / 2;
+    float wf[NPAIR];
     {
         const float* w = a.w + c * a.w_cs;
 #pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) {
-            const int ky = 2 * kk + h;
-#pragma unroll
-            for (int j = 0; j < KS; ++j) wf[kk][j] = (r < a.F && ky < KS) ? w[r * KS * KS + ky * KS + j] : 0.f;
-        }
+        for (int i = 0; i < NPAIR; ++i) wf[i] = (r < a.F && 2 * i + h < T) ? w[r * T + 2 * i + h] : 0.f;
     }
     float bv[16];
 #pragma unroll
@@ -125,14 +125,17 @@ __global__ __launch_bounds__(256) void conv1_fwd_f32_kernel(Conv1Args a) {
                 for (int d = 0; d < 2; ++d)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
-                const float* p = my + (2 * py + half + h) * LW + 2 * pxx;
+                const float* p = my + (2 * py + half) * LW + 2 * pxx;
+                const float* p1 = p + h;                          // pairs inside a filter row
+                const float* p2 = p + h * (LW - (KS - 1));        // pairs that wrap to the next row
 #pragma unroll
-                for (int kk = 0; kk < NKK; ++kk)
+                for (int i = 0; i < NPAIR; ++i) {
+                    const int t0 = 2 * i, ky = t0 / KS, kx = t0 % KS;
+                    const float* q = (kx == KS - 1) ? p2 : p1;
 #pragma unroll
-                    for (int j = 0; j < KS; ++j)
-#pragma unroll
-                        for (int d = 0; d < 2; ++d)
-                            acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[kk][j], p[2 * kk * LW + d + j], acc[d], 0, 0, 0);
+                    for (int d = 0; d < 2; ++d)
+                        acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[i], q[ky * LW + kx + d], acc[d], 0, 0, 0);
+                }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     if (half == 0) { best[e] = acc[0][e]; qi[e] = 0; }

@@ -817,8 +817,11 @@ __global__ __launch_bounds__(256, 2) void conv2_dgrad_dense_kernel(DgradArgs a) 
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         if (pass) __syncthreads();                 // all reads of the previous pass's images and slices are done
-        for (int i = tid; i < NS * IMG / 16; i += 256)
-            *reinterpret_cast<float4*>(gimg + i * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        // the routing below writes all four pixels of every window (zeros where the window's arg-max is elsewhere), i.e. the
+        // whole interior: only the halo needs the zero fill, once
+        if (pass == 0)
+            for (int i = tid; i < NS * IMG / 16; i += 256)
+                *reinterpret_cast<float4*>(gimg + i * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
         {
             bf16x8 w0[WROUNDS];
             wload(0, pass, w0);
@@ -849,6 +852,8 @@ __global__ __launch_bounds__(256, 2) void conv2_dgrad_dense_kernel(DgradArgs a) 
                 }
             }
         }
+        // (the second pass's gradient loaded into registers before the first pass's tap loop: slower, 203.8 us against 194.4
+        //  for 50 clients 5x5, 1357 against 1342 for 1000 clients 3x3)
         __syncthreads();
         const bool left = (wave >> 1) == pass;     // (wave-uniform) this wave owns the left-over pixels in this pass
 

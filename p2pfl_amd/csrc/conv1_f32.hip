@@ -284,30 +284,31 @@ __global__ __launch_bounds__(256) void conv1_wgrad_f32_kernel(Conv1WgradArgs a) 
         const bool has_next = b + (int)gridDim.x < a.B;
         if (has_next) st.load(a, c, b + gridDim.x);          // global loads fly while this image is consumed
         const Conv1WgradSmemF& sm = smem[cur];
-        for (int py = wave; py < P1; py += 4) {
+        // wave q takes pool corner q of ALL 14 window rows: 14 x 7 x NJN MFMAs per wave and sample, the same for every wave
+        // (rows dealt to the waves - 4 / 4 / 3 / 3 - made the sample as long as 16 corner rows on the heavy waves)
+        const int q = wave;
+#pragma unroll 2
+        for (int py = 0; py < P1; ++py) {
             // pooled gradient + codes of the 7 windows px = 7h .. 7h+6 of filter r
             const float* gr = sm.g + r * WG_GS + py * P1 + 7 * h;
             const uint8_t* cr = sm.code + r * WG_CS + py * P1 + 7 * h;
             float gv[7]; int cv[7];
 #pragma unroll
             for (int j = 0; j < 7; ++j) { gv[j] = gr[j]; cv[j] = cr[j]; }
+            const float* bp[NJN];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float* bp[NJN];
+            for (int jn = 0; jn < NJN; ++jn) {
+                // pixel of window px for tap (ky, kx): (2py + dy + ky, 2px + dx + kx)
+                const int v = (q & 1) + kx[jn];
+                bp[jn] = sm.img[v & 1] + (2 * py + (q >> 1) + ky[jn]) * WG_HW + 7 * h + (v >> 1);
+            }
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const float av = cv[j] == q ? gv[j] : 0.f;
 #pragma unroll
                 for (int jn = 0; jn < NJN; ++jn) {
-                    // pixel of window px for tap (ky, kx): (2py + dy + ky, 2px + dx + kx)
-                    const int v = (q & 1) + kx[jn];
-                    bp[jn] = sm.img[v & 1] + (2 * py + (q >> 1) + ky[jn]) * WG_HW + 7 * h + (v >> 1);
-                }
-#pragma unroll
-                for (int j = 0; j < 7; ++j) {
-                    const float av = cv[j] == q ? gv[j] : 0.f;
-#pragma unroll
-                    for (int jn = 0; jn < NJN; ++jn) {
-                        const float bvv = is_tap[jn] ? bp[jn][j] : (is_one[jn] ? 1.f : 0.f);
-                        acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvv, acc[jn], 0, 0, 0);
-                    }
+                    const float bvv = is_tap[jn] ? bp[jn][j] : (is_one[jn] ? 1.f : 0.f);
+                    acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvv, acc[jn], 0, 0, 0);
                 }
             }
         }

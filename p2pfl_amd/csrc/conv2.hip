@@ -1332,13 +1332,14 @@ __global__ __launch_bounds__(512, 1) void conv2_wgrad_split_kernel(WgradArgs a) 
 // (50 clients: 5 batch splits = 250 blocks on 256 CUs; the two-tile form has 200 or 400), and the 2 x T (row tile, tap)
 // units are dealt to the 8 waves as 7/6/6/6 + 6/7/6/6 (5x5; 3x3: 3/2/2/2 + 2/3/2/2) - waves w and w + 4 share a SIMD, so
 // every SIMD carries 13 / 13 / 12 / 12 units and the two bias units ride on the light ones.
-template <int KS>
-__global__ __launch_bounds__(512, 1) void conv2_wgrad_split64_kernel(WgradArgs a) {
+template <int KS, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void conv2_wgrad_split64_kernel(WgradArgs a) {
     constexpr int NS = 3;
+    constexpr int NTHR = 64 * NW, TG = NW / 2;             // threads; tap groups per row tile
     using G = Geo<KS>;
     constexpr int T = G::T;
-    constexpr int NTAP = (T + 3) / 4;                    // most taps per wave (T % 4 == 1: one wave of a row tile has it)
-    static_assert(T % 4 == 1, "tap split assumes 25 or 9 taps");
+    constexpr int NTAP = (T + TG - 1) / TG;              // most taps per wave (T % TG == 1: one wave of a row tile has it)
+    static_assert(T % TG == 1 && TG % 4 == 0, "tap split assumes 25 or 9 taps on 4 or 8 groups");
     constexpr int XRS = G::IW * 64 + ((((P1 - G::IW) * 64) % 256) + 256) % 256;
     constexpr int XROWS = G::IW + 1;                     // +1 zero row: K padding (pixels 196..207) reads it
     constexpr int GPS = 128;                             // all 64 gradient channels
@@ -1354,10 +1355,10 @@ __global__ __launch_bounds__(512, 1) void conv2_wgrad_split64_kernel(WgradArgs a
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mt = wv >> 2;                              // row tile (32 gradient channels) of this wave
-    const int jj = ((wv & 3) - mt) & 3;                  // its tap group, rotated by the row tile (SIMD balance)
-    const int t_begin = jj * (T / 4) + (jj > 0 ? 1 : 0);
-    const int ntap = T / 4 + (jj == 0 ? 1 : 0);         // NTAP or NTAP - 1
+    const int mt = wv / TG;                              // row tile (32 gradient channels) of this wave
+    const int jj = ((wv % TG) - mt) & (TG - 1);          // its tap group, rotated by the row tile (SIMD balance)
+    const int t_begin = jj * (T / TG) + (jj > 0 ? 1 : 0);
+    const int ntap = T / TG + (jj == 0 ? 1 : 0);        // NTAP or NTAP - 1
     const bool do_bias = jj == 2;                        // wave-uniform; a light wave on SIMD 2 (mt 0) / 3 (mt 1)
     int toff[NTAP];
 #pragma unroll
@@ -1366,9 +1367,9 @@ __global__ __launch_bounds__(512, 1) void conv2_wgrad_split64_kernel(WgradArgs a
         toff[j] = (t / KS) * XRS + (t % KS) * 64;
     }
 
-    for (int i = tid; i < NS * XIMG / 16; i += 512)
+    for (int i = tid; i < NS * XIMG / 16; i += NTHR)
         *reinterpret_cast<float4*>(ximg + i * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = tid; i < NS * GIMG / 16; i += 512)
+    for (int i = tid; i < NS * GIMG / 16; i += NTHR)
         *reinterpret_cast<float4*>(gimg + i * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // lane roles in the transposed reads
@@ -1377,12 +1378,13 @@ __global__ __launch_bounds__(512, 1) void conv2_wgrad_split64_kernel(WgradArgs a
     const int ch_off = ((grp & 1) * 16 + 4 * pq) * 2;                // byte offset of its 4 channels (X; G: + 64 mt)
 
     // staging roles (global -> registers -> LDS)
-    float xv[2][8]; float gv[8]; int qc[8];
+    constexpr int XU = (CELLS1 * 4 + NTHR - 1) / NTHR;   // image staging tasks per thread: 2 / 1
+    float xv[XU][8]; float gv[8]; int qc[8];
     auto prefetch = [&](int b) {
         const float* a1 = a.a1 + c * a.a1_cs + (size_t)b * CIN * CELLS1;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int task = tid + 512 * u;
+        for (int u = 0; u < XU; ++u) {
+            const int task = tid + NTHR * u;
             if (task < CELLS1 * 4) {
                 const float* src = a1 + (task & 3) * 8 * CELLS1 + (task >> 2);
 #pragma unroll
@@ -1399,8 +1401,8 @@ __global__ __launch_bounds__(512, 1) void conv2_wgrad_split64_kernel(WgradArgs a
     };
     auto commit = [&]() {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int task = tid + 512 * u;
+        for (int u = 0; u < XU; ++u) {
+            const int task = tid + NTHR * u;
             if (task < CELLS1 * 4) {
                 const int p = task >> 2;
                 bf16x8 tv[NS];
@@ -1686,8 +1688,9 @@ static void wgrad_split(int K, int B, int KS, int cus, int& np, int& ns) {
 }
 
 // Which filter sizes take the 64-channel blocks of conv2_wgrad_split64_kernel: 3x3 (1000 clients 1741 -> 1421 us, 50 clients
-// 124 -> 112). The 5x5 instance needs 7 accumulator tiles per wave beside the staging registers and spills (50 clients:
-// 250 us against 225 for the two-row-tile form). P2PFL_WGRAD_WIDE=0 / 1: none / both (A/B runs).
+// 124 -> 112). 5x5 does not pay: with 8 waves a wave has 7 accumulator tiles beside the staging registers and spills (50
+// clients: 250 us against 225-230 for the two-row-tile form), with 16 waves (4 tiles per wave, the instance kept) the
+// 128-register file of a wave spills as well (255 us). P2PFL_WGRAD_WIDE=0 / 1: none / both (A/B runs).
 static bool wgrad_wide_for(int KS) {
     static const int mode = [] { const char* e = getenv("P2PFL_WGRAD_WIDE"); return e ? atoi(e) : -1; }();
     return mode < 0 ? KS == 3 : mode != 0;
@@ -1757,8 +1760,8 @@ P2PFL_API int p2pfl_conv2_wgrad_opt(const float* g, long g_cs, const uint8_t* co
                     make_opt_epi(opt)};
         if (wgrad_wide_for(KS)) {
             const dim3 grid(cdiv(K, 8) * 8 * ns);
-            if (KS == 5) hipLaunchKernelGGL(conv2_wgrad_split64_kernel<5>, grid, dim3(512), 0, stream, a);
-            else hipLaunchKernelGGL(conv2_wgrad_split64_kernel<3>, grid, dim3(512), 0, stream, a);
+            if (KS == 5) hipLaunchKernelGGL((conv2_wgrad_split64_kernel<5, 16>), grid, dim3(1024), 0, stream, a);
+            else hipLaunchKernelGGL((conv2_wgrad_split64_kernel<3, 8>), grid, dim3(512), 0, stream, a);
         } else {
         const dim3 grid(cdiv(K, 8) * 8 * 2 * ns);
         if (KS == 5) hipLaunchKernelGGL((conv2_wgrad_split_kernel<5, SPLIT_TERMS>), grid, dim3(512), 0, stream, a);

@@ -105,8 +105,10 @@ template <int KS, int S>
 __device__ __forceinline__ void conv2_fwd_f32_body(const FwdArgs& a) {
     using G = GeoF<KS>;
     constexpr int NWIN = S * CELLS2;           // 98 / 49
-    constexpr int NTILE = (NWIN + 7) / 8;      // 13 / 7
-    constexpr int MU = (NTILE + 1) / 2;        // row tiles per wave: 7 (even tiles) or 6 (odd tiles) / 4 or 3
+    constexpr int NFULL = NWIN / 8;            // full row tiles: 12 / 6
+    constexpr int REM = NWIN % 8;              // left-over windows: 2 / 1 (on the 16-row instruction, see below)
+    constexpr int MU = NFULL / 2;              // row tiles per wave: 6 / 3
+    static_assert(NFULL % 2 == 0 && REM <= 4, "tiles split evenly over the two tile parities; left-over fits 16 rows");
     constexpr int XN = S * CIN * G::CS;
     __shared__ __attribute__((aligned(16))) float ximg[(XN + 3) / 4 * 4];
     __shared__ __attribute__((aligned(16))) float wbuf[2][CIN * COUT];
@@ -142,17 +144,28 @@ __device__ __forceinline__ void conv2_fwd_f32_body(const FwdArgs& a) {
     __syncthreads();
 
     const int half = wave & 1, tile0 = wave >> 1;
-    const int ntile = (NTILE - tile0 + 1) / 2;
     int abase[MU];
 #pragma unroll
     for (int i = 0; i < MU; ++i) {
-        int W = (tile0 + 2 * i) * 8 + (r >> 2);
-        if (W >= NWIN) W = 0;                  // also the whole surplus tile of the odd-tile waves
+        const int W = (tile0 + 2 * i) * 8 + (r >> 2);
         const int q = r & 3, s = W / CELLS2, cell = W % CELLS2;
         const int y = 2 * (cell / P2) + (q >> 1), x = 2 * (cell % P2) + (q & 1);
         abase[i] = (s * CIN + h) * G::CS + y * G::IW + x;
     }
+    // The REM windows past the last full tile run on v_mfma_f32_16x16x4_f32 (lane l: row l & 15 = window (l & 15) >> 2,
+    // corner l & 3 - rows past the real windows repeat the first one -, k = l >> 4; B: column 16 wave + (l & 15)): a
+    // 49-window sample used to be 7 row tiles issued as 8 (two waves recomputed a clamped tile), now 6 + this.
+    int lbase, lwoff;
+    {
+        const int lw = (lane & 15) >> 2;
+        const int W = NFULL * 8 + (lw < REM ? lw : 0);
+        const int q = lane & 3, s = W / CELLS2, cell = W % CELLS2;
+        const int y = 2 * (cell / P2) + (q >> 1), x = 2 * (cell % P2) + (q & 1);
+        lbase = (s * CIN + (lane >> 4)) * G::CS + y * G::IW + x;
+        lwoff = (lane >> 4) * COUT + 16 * wave + (lane & 15);
+    }
     f32x16 acc[MU];
+    f32x4 accl = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < MU; ++i)
 #pragma unroll
@@ -175,11 +188,16 @@ __device__ __forceinline__ void conv2_fwd_f32_body(const FwdArgs& a) {
 #pragma unroll
         for (int s = 0; s < CIN / 2; ++s) {
             const float bv = wb[2 * s * COUT];
-            // (no `i < ntile` guard: a wave with one tile less recomputes a clamped tile instead - it would wait for
-            //  the others at the barrier anyway, and the guarded form compiles to a branch + accumulator copies per MFMA)
 #pragma unroll
             for (int i = 0; i < MU; ++i)
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[i][2 * s * G::CS], bv, acc[i], 0, 0, 0);
+        }
+        {
+            const float* al = ximg + lbase + toff;
+            const float* bl = wbuf[t & 1] + lwoff;
+#pragma unroll
+            for (int s = 0; s < CIN / 4; ++s)
+                accl = __builtin_amdgcn_mfma_f32_16x16x4f32(al[4 * s * G::CS], bl[4 * s * COUT], accl, 0, 0, 0);
         }
         if (t + 1 < G::T) {
 #pragma unroll
@@ -197,23 +215,25 @@ __device__ __forceinline__ void conv2_fwd_f32_body(const FwdArgs& a) {
     uint8_t* code_s = reinterpret_cast<uint8_t*>(ximg + S * COUT * CELLS2);
     const int n = half * 32 + r;
     const float bv = a.bias[c * a.b_cs + n];
+    auto pool = [&](float v0, float v1, float v2, float v3, float bias_n, int nn, int W) {
+        float best = v0; int q = 0;
+        if (v1 > best) { best = v1; q = 1; }
+        if (v2 > best) { best = v2; q = 2; }
+        if (v3 > best) { best = v3; q = 3; }
+        best += bias_n;
+        if (!(best > 0.f)) { best = 0.f; q = 4; }
+        const int o = ((W / CELLS2) * COUT + nn) * CELLS2 + W % CELLS2;     // == the global layout of the block
+        out_s[o] = best;
+        code_s[o] = (uint8_t)q;
+    };
 #pragma unroll
-    for (int i = 0; i < MU; ++i) {
-        if (i >= ntile) continue;
+    for (int i = 0; i < MU; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int W = (tile0 + 2 * i) * 8 + 2 * g + h;
-            if (W >= NWIN) continue;
-            float best = acc[i][4 * g]; int q = 0;
-            if (acc[i][4 * g + 1] > best) { best = acc[i][4 * g + 1]; q = 1; }
-            if (acc[i][4 * g + 2] > best) { best = acc[i][4 * g + 2]; q = 2; }
-            if (acc[i][4 * g + 3] > best) { best = acc[i][4 * g + 3]; q = 3; }
-            best += bv;
-            if (!(best > 0.f)) { best = 0.f; q = 4; }
-            const int o = ((W / CELLS2) * COUT + n) * CELLS2 + W % CELLS2;     // == the global layout of the block
-            out_s[o] = best;
-            code_s[o] = (uint8_t)q;
-        }
+        for (int g = 0; g < 4; ++g)
+            pool(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3], bv, n, (tile0 + 2 * i) * 8 + 2 * g + h);
+    if ((lane >> 4) < REM) {     // 16 x 16 accumulator: lane = column, registers = rows 4 (lane >> 4) .. + 3 = one window
+        const int nn = 16 * wave + (lane & 15);
+        pool(accl[0], accl[1], accl[2], accl[3], a.bias[c * a.b_cs + nn], nn, NFULL * 8 + (lane >> 4));
     }
     __syncthreads();
     const int nvalid = min(S, a.B - b0) * COUT * CELLS2;

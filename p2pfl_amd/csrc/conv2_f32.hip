@@ -260,11 +260,13 @@ struct DgradArgs {
 
 // CH = channels of the gradient image resident at a time: 64 (one pass, 100 KB of LDS) or 32 (two passes over the
 // taps, 50 KB and <= 128 registers: the variant that fits beside the fused update kernel, see the forward kernel).
+// 196 pixels are six full 32-row tiles and four pixels (the first form issued 8 tiles: two per wave). The twelve (tile,
+// channel half of the pass) units are dealt three to a wave - wave w reduces channels (w & 1) CH / 2 .. + CH / 2 - 1 over
+// tiles 3 (w >> 1) + {0, 1, 2}; the two waves of a tile triple add their accumulators through LDS at the end, in a fixed
+// order - and the four left-over pixels run on v_mfma_f32_16x16x4_f32: wave w = (16-column tile w & 1, channel half w >> 1).
 template <int KS, int CH>
 __device__ __forceinline__ void conv2_dgrad_f32_body(const DgradArgs& a) {
     using G = GeoF<KS>;
-    constexpr int NTILE = (CELLS1 + 31) / 32;   // 7
-    constexpr int MT = (NTILE + 3) / 4;         // (2,2,2,1)
     constexpr int GN = CH * G::CS;
     constexpr int WU = CH * CIN / 4 / 256;      // float4 of a weight slice per thread: 2 / 1
     __shared__ __attribute__((aligned(16))) float gimg[(GN + 3) / 4 * 4];
@@ -275,20 +277,25 @@ __device__ __forceinline__ void conv2_dgrad_f32_body(const DgradArgs& a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+    const int kh = wave & 1, t0 = 3 * (wave >> 1);
 
-    int abase[MT];
+    int abase[3];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        int p = (wave + 4 * i) * 32 + r;
-        if (p >= CELLS1) p = 0;
-        abase[i] = h * G::CS + (p / P1) * G::IW + (p % P1);
+    for (int i = 0; i < 3; ++i) {
+        const int p = (t0 + i) * 32 + r;
+        abase[i] = (h + kh * (CH / 2)) * G::CS + (p / P1) * G::IW + (p % P1);
     }
-    f32x16 acc[MT];
+    // left-over pixels: lane l -> row l & 15 (pixel 192 + (l & 3), rows >= 4 repeat it), k = l >> 4; B column 16 (wave & 1)
+    // + (l & 15); this wave's channels (wave >> 1) CH / 2 .. + CH / 2 - 1
+    const int lp = 192 + (lane & 3);
+    const int lbase = ((wave >> 1) * (CH / 2) + (lane >> 4)) * G::CS + (lp / P1) * G::IW + (lp % P1);
+    const int lwoff = ((wave >> 1) * (CH / 2) + (lane >> 4)) * CIN + 16 * (wave & 1) + (lane & 15);
+    f32x16 acc[3];
+    f32x4 accl = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-    const int ntile = (NTILE - wave + 3) / 4;
 
 #pragma unroll 1
     for (int pass = 0; pass < COUT / CH; ++pass) {
@@ -325,17 +332,24 @@ __device__ __forceinline__ void conv2_dgrad_f32_body(const DgradArgs& a) {
                 for (int u = 0; u < WU; ++u)
                     wnext[u] = reinterpret_cast<const f32x4*>(wd + (t + 1) * COUT * CIN)[tid + 256 * u];
             }
-            const float* wb = wbuf[t & 1] + h * CIN + r;
+            const float* wb = wbuf[t & 1] + (h + kh * (CH / 2)) * CIN + r;
             const int toff = ky * G::IW + kx;
-            const float* ap[MT];
+            const float* ap[3];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) ap[i] = gimg + abase[i] + toff;
+            for (int i = 0; i < 3; ++i) ap[i] = gimg + abase[i] + toff;
 #pragma unroll
-            for (int s = 0; s < CH / 2; ++s) {
+            for (int s = 0; s < CH / 4; ++s) {
                 const float bv = wb[2 * s * CIN];
 #pragma unroll
-                for (int i = 0; i < MT; ++i)      // (unguarded on purpose, see the forward kernel)
+                for (int i = 0; i < 3; ++i)
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[i][2 * s * G::CS], bv, acc[i], 0, 0, 0);
+            }
+            {
+                const float* al = gimg + lbase + toff;
+                const float* bl = wbuf[t & 1] + lwoff;
+#pragma unroll
+                for (int s = 0; s < CH / 8; ++s)
+                    accl = __builtin_amdgcn_mfma_f32_16x16x4f32(al[4 * s * G::CS], bl[4 * s * CIN], accl, 0, 0, 0);
             }
             if (t + 1 < G::T) {
 #pragma unroll
@@ -346,18 +360,38 @@ __device__ __forceinline__ void conv2_dgrad_f32_body(const DgradArgs& a) {
         }
     }
 
-    // ---- epilogue: lane = input channel, registers 4g..4g+3 = four consecutive pixels -> float4
-    float* dst = a.da1 + c * a.da1_cs + ((size_t)b * CIN + r) * CELLS1;
+    // ---- the odd waves hand their channel halves over (the loop's last barrier freed the image)
+    float* red = gimg;                          // [2 triples][3 tiles][16][64] + left-over [4 waves][4][64]
+    float* redl = red + 2 * 3 * 16 * 64;
+    static_assert(GN >= 2 * 3 * 16 * 64 + 4 * 4 * 64, "the exchange must fit into the image buffer");
+    if (kh) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        if (i >= ntile) continue;
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int p = (wave + 4 * i) * 32 + 8 * g + 4 * h;
-            if (p < CELLS1)
-                *reinterpret_cast<float4*>(dst + p) =
-                    make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
-        }
+            for (int e = 0; e < 16; ++e) red[(((wave >> 1) * 3 + i) * 16 + e) * 64 + lane] = acc[i][e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) redl[(wave * 4 + e) * 64 + lane] = accl[e];
+    __syncthreads();
+    if (!kh) {     // lane = input channel, registers 4g..4g+3 = four consecutive pixels -> float4
+        float* dst = a.da1 + c * a.da1_cs + ((size_t)b * CIN + r) * CELLS1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int p = (t0 + i) * 32 + 8 * g + 4 * h;
+                const float* o = red + (((wave >> 1) * 3 + i) * 16 + 4 * g) * 64 + lane;
+                *reinterpret_cast<float4*>(dst + p) = make_float4(acc[i][4 * g] + o[0], acc[i][4 * g + 1] + o[64],
+                                                                  acc[i][4 * g + 2] + o[128], acc[i][4 * g + 3] + o[192]);
+            }
+    } else if (lane < 16) {
+        // left-over pixels: wave 1 finishes column tile 0 (waves 0 + 2: the two channel halves), wave 3 column tile 1 (1 + 3)
+        const int j = wave >> 1;
+        const int ci = 16 * j + lane;
+        const float* p0 = redl + (j * 4) * 64 + lane;
+        const float* p1 = redl + ((2 + j) * 4) * 64 + lane;
+        float* dst = a.da1 + c * a.da1_cs + ((size_t)b * CIN + ci) * CELLS1 + 192;
+        *reinterpret_cast<float4*>(dst) = make_float4(p0[0] + p1[0], p0[64] + p1[64], p0[128] + p1[128], p0[192] + p1[192]);
     }
 }
 

@@ -25,6 +25,8 @@
 //
 // Reference layers: fedstellar/learning/pytorch/mnist/models/cnn.py:138-142,152-154 and
 // fedstellar/learning/pytorch/femnist/models/cnn.py:137-139,147-148.
+#include <type_traits>
+
 #include "conv_f32.h"
 #include "opt_epi.h"
 
@@ -554,17 +556,25 @@ __device__ __forceinline__ void conv2_wgrad_f32_body(const WgradArgs& a) {
         __syncthreads();
         if (PREFETCH && item + 1 < b_end) prefetch(item + 1);
 
+        // the sample's MFMA loop with a compile-time tap count (wave-uniform choice): a group with one tap less used to
+        // recompute its last tap - 16 MFMAs per k-step and block for the 12 / 13 taps of a 5x5 half
+        auto mm = [&](auto nt_c) {
+            constexpr int NT = decltype(nt_c)::value;
 #pragma unroll 1
-        for (int y = 0; y < P1; ++y) {
+            for (int y = 0; y < P1; ++y) {
 #pragma unroll
-            for (int xs = 0; xs < P1 / 2; ++xs) {
-                const float av = gp[y * P1 + 2 * xs];
-                bsum += av;
+                for (int xs = 0; xs < P1 / 2; ++xs) {
+                    const float av = gp[y * P1 + 2 * xs];
+                    bsum += av;
 #pragma unroll
-                for (int j = 0; j < NTAP; ++j)    // (unguarded: a group with one tap less recomputes its last tap)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xp[j][y * G::IW + 2 * xs], acc[j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xp[j][y * G::IW + 2 * xs], acc[j], 0, 0, 0);
+                }
             }
-        }
+        };
+        if (ntap == NTAP) mm(std::integral_constant<int, NTAP>{});
+        else if (ntap == NTAP - 1) mm(std::integral_constant<int, NTAP - 1>{});
+        else mm(std::integral_constant<int, (NTAP > 2 ? NTAP - 2 : 0)>{});
     }
 
     const int ci = r;

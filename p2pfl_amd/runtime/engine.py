@@ -476,12 +476,14 @@ class HipEngine(ShardEngine):
         # big linear layers: weight gradient fused with the optimizer update (gradient never hits HBM)
         self._fused = set()
         # The fused update of a big layer can also emit that layer's data gradient (one pass over the weights less),
-        # at the price of the convolution backward no longer running BESIDE the update. A gain where nothing overlaps
-        # (default policy "fp32": 310 -> 290 ms per headline round), a loss where something does ("fp32-mfma":
-        # 336 -> 340 ms, its small-footprint convolution blocks take whole CUs from the update; "bf16": the short
-        # convolutions hide completely). P2PFL_FUSE_DGRAD=0/1 overrides for the fp32 policies.
+        # at the price of the convolution backward no longer running BESIDE the update of the same clients - which the
+        # two-group schedule gives back (the other group's convolution chain runs there). Both fp32 policies take it:
+        # "fp32" 310 -> 290 ms per headline round when it was introduced; "fp32-mfma" lost with its first convolution
+        # kernels (336 -> 340 ms) and wins since their tile / tap counts are exact (293.9 -> 291.2 ms, with the
+        # small-footprint convolution variants inside the groups 290.4; tools/probe/mfma_fuse.sh). "bf16": the short
+        # convolutions hide completely. P2PFL_FUSE_DGRAD=0/1 overrides for the fp32 policies.
         env = os.environ.get("P2PFL_FUSE_DGRAD")
-        self._fuse_dgrad = self.precision != "bf16" and (self.precision == "fp32" if env is None else env != "0")
+        self._fuse_dgrad = self.precision != "bf16" and (self.precision in ("fp32", "fp32-mfma") if env is None else env != "0")
         self._adam_ranges = [(0, L.row_stride)]      # slab ranges the element-wise optimizer kernel owns
         if o.kind in ("adam", "sgd") and fuse_optimizer and not os.environ.get("P2PFL_NO_FUSE"):
             cut = []
@@ -1180,7 +1182,10 @@ class HipEngine(ShardEngine):
         last_valid = n - (steps - 1) * B
         for ph in ("Train", "Validation"):
             self.stats[ph].zero_()
-        cores = bool(os.environ.get("P2PFL_GROUPS_CORES"))      # experiment: small-footprint convolution variants
+        # small-footprint convolution variants inside the groups: the fp32-MFMA kernels (290.4 vs 291.2 ms); not the
+        # exact-split ones. P2PFL_GROUPS_CORES=0/1 overrides.
+        env = os.environ.get("P2PFL_GROUPS_CORES")
+        cores = self.precision == "fp32-mfma" if env is None else env not in ("", "0")
         done = [None] * G                    # side stream finished the convolution chain (next forward included) of group g
         t = 0
         for e in range(epochs):

@@ -1,6 +1,7 @@
 """HIP shard engine against the eager (torch.nn + autograd, fp32) engine."""
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -18,6 +19,35 @@ def _pair(name, K=3, n=64, n_val=16, n_test=40, fuse=True, precision="fp32"):
     h.set_data(*data)
     e.set_data(*data)
     return spec, h, e
+
+
+def _near_tie_pool_flips(spec, m, xb, h, k):
+    """Max-pool decisions of engine ``h`` (client ``k``) that differ from a float64 evaluation of the same network, and
+    the largest relative top-2 gap among them. A 2x2 window whose two largest values agree to fp32 round-off is a coin
+    flip for ANY fp32 evaluation order (ours, cuDNN's, MIOpen's); the gradient is then routed to the other pixel and
+    whole-network weight gradients move by ~1e-3 although every kernel is exact (tools/probe/dbg_grad.py)."""
+    P = {n: p.detach().double() for n, p in m.named_parameters()}
+    if "conv1.weight" not in P or "conv2.weight" not in P:
+        return 0, 0.0
+    B = xb.shape[0]
+    x = xb.view(B, 1, 28, 28).double()
+    flips, worst = 0, 0.0
+    for i, cname in enumerate(("conv1", "conv2")):
+        ks = spec.layers[i].ksize
+        pre = F.conv2d(x, P[f"{cname}.weight"], P[f"{cname}.bias"], padding=ks // 2)
+        C, S = pre.shape[1], pre.shape[2] // 2
+        win = pre.view(B, C, S, 2, S, 2).permute(0, 1, 2, 4, 3, 5).reshape(B, C, S * S, 4)
+        top2 = win.topk(2, -1).values
+        ref = torch.where(top2[..., 0] <= 0, torch.full_like(win.argmax(-1), 4), win.argmax(-1))
+        diff = ref != h.code[i][k].view(B, C, S * S).long()
+        if diff.any():
+            scale = win.abs().amax(-1).clamp(min=1e-30)
+            gap = ((top2[..., 0] - top2[..., 1]).abs() / scale)[diff]
+            dead_gap = (top2[..., 0].abs() / scale)[diff]                 # max ~ 0: ReLU on / off
+            flips += int(diff.sum())
+            worst = max(worst, float(torch.minimum(gap, dead_gap).max()))
+        x = F.max_pool2d(pre.relu(), 2, 2)
+    return flips, worst
 
 
 @pytest.mark.parametrize("precision", ["fp32-mfma", "fp32", "bf16"])
@@ -39,6 +69,11 @@ def test_first_step_gradients_match_autograd(name, precision):
         loss = m.criterion(m(xb), yb)
         loss.backward()
         assert abs(h.stats["Train"].loss_sum[k].item() / B - loss.item()) < (1e-5 if f32 else 2e-2) * max(1.0, loss.item())
+        # fp32 policies: a pool window tied to round-off may be decided the other way (never more than a few of the
+        # ~300 000 decisions of a client, each with a top-2 gap at the fp32 round-off level); such a client is compared
+        # loosely, every other one to round-off
+        flips, gap = _near_tie_pool_flips(spec, m, xb, h, k) if f32 else (0, 0.0)
+        assert flips <= 3 and gap < 1e-5, f"{name}: {flips} pool decisions differ from float64, top-2 gap {gap:.1e}"
         for pname, p in m.named_parameters():
             g = h.grad_view(pname)[k]
             # fp32 (the default policy): whole-network gradients agree with autograd to round-off.
@@ -48,7 +83,7 @@ def test_first_step_gradients_match_autograd(name, precision):
             err = (g - p.grad).norm() / p.grad.norm().clamp(min=1e-12)
             cos = torch.nn.functional.cosine_similarity(g.flatten(), p.grad.flatten(), dim=0)
             if f32:
-                assert err < 1e-4, f"{name} {pname}: rel err {err:.3e}"
+                assert err < (1e-4 if flips == 0 else 1e-2), f"{name} {pname}: rel err {err:.3e}"
             else:
                 assert err < 0.12 and cos > 0.99, f"{name} {pname}: rel err {err:.3e} cos {cos:.5f}"
 

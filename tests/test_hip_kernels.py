@@ -836,7 +836,8 @@ def _slabs(K, P, n=3):
 
 
 @pytest.mark.parametrize("K,B,nv,In,C,mask", [(3, 32, 32, 2048, 10, True), (2, 32, 12, 128, 10, True),
-                                              (2, 20, 20, 3136, 16, False), (5, 7, 5, 260, 3, True)])
+                                              (2, 20, 20, 3136, 16, False), (5, 7, 5, 260, 3, True),
+                                              (4, 32, 12, 2048, 10, True), (2, 9, 4, 1100, 5, False)])
 @pytest.mark.parametrize("kind", [None, "adam", "sgd"])
 @pytest.mark.parametrize("form", ["one-kernel", "sliced"])
 def test_linear_head_matches_torch(K, B, nv, In, C, mask, kind, form):

@@ -632,7 +632,7 @@ __device__ __forceinline__ void fused_update_strip(const WgradAdamArgs& a, const
 }
 
 template <bool FRESH, int D>
-__global__ __launch_bounds__(256, D >= 8 ? 1 : 2)
+__global__ __launch_bounds__(256, D >= 4 ? 1 : 2)
 void linear_wgrad_adam_dgrad_kernel(WgradAdamArgs a, float* dx_all, long dx_cs) {
     constexpr int BK = GEMM_BK, LDK = BK + lds_pad<float>();
     static_assert(LDK == GEMM_BK + 4, "fp32 LDS rows carry 4 floats of padding");
@@ -817,20 +817,24 @@ P2PFL_API int p2pfl_linear_wgrad_adam_dgrad(const float* dy, long dy_cs, const f
                     AdamHyper{lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
                               (float)(1.0 / sqrt(bc2)), bc, fresh}, sidx, s_cs, 0};
     const dim3 grid(cdiv(In + 1, 128), K);
-    // rows in flight per lane (ring depth of the epilogue pipeline). 8 rows = 24 float4 per lane need the whole register
-    // file (467 registers: ONE workgroup per CU) and win: 100 clients x 3136x2048 on MI355X 3.26 ms (no pipeline)
-    // -> 3.08 (depth 2, two workgroups per CU, spills) -> 3.01 ms = 5.2 TB/s, which is what ANY in-place
-    // 3-read / 3-write fp32 stream reaches on this part whatever its geometry (tools/probe/stream_geom.hip).
-    // P2PFL_UPDATE_DEPTH=2 selects the shallow variant (experiments).
-    static const int depth = [] { const char* e = getenv("P2PFL_UPDATE_DEPTH"); return e ? atoi(e) : 8; }();
+    // rows in flight per lane (ring depth of the epilogue pipeline). Alone, 8 rows = 24 float4 per lane win - they need
+    // the whole register file (467 registers: ONE workgroup per CU): 100 clients x 3136x2048 on MI355X 3.26 ms (no
+    // pipeline) -> 3.08 (depth 2, two workgroups per CU, spills) -> 3.01 ms = 5.2 TB/s, which is what ANY in-place
+    // 3-read / 3-write fp32 stream reaches on this part whatever its geometry (tools/probe/stream_geom.hip). Inside the
+    // two-group round 4 rows (376 registers, still one workgroup per CU, 136 registers per SIMD left for a co-resident
+    // wave of the other group's chain) are as fast or faster everywhere (tools/probe/depth_ab.sh: headline 246.7 -> 244.9
+    // ms, cnn100-encrypted-churn 244.1 -> 241.2, fp32-mfma headline 290.1 -> 286.3, 200 / 1000 nodes on the card 484.0 /
+    // 483.6 and 2379 / 2373): the default. P2PFL_UPDATE_DEPTH=2 / 8 / 16 select the other variants (experiments).
+    static const int depth = [] { const char* e = getenv("P2PFL_UPDATE_DEPTH"); return e ? atoi(e) : 4; }();
 #define P2PFL_LAUNCH_FUSED(D_)                                                                                          \
     do {                                                                                                                \
         if (fresh) hipLaunchKernelGGL((linear_wgrad_adam_dgrad_kernel<true, D_>), grid, dim3(256), 0, stream, a, dx, dx_cs); \
         else hipLaunchKernelGGL((linear_wgrad_adam_dgrad_kernel<false, D_>), grid, dim3(256), 0, stream, a, dx, dx_cs);   \
     } while (0)
     if (depth == 2) P2PFL_LAUNCH_FUSED(2);
+    else if (depth == 8) P2PFL_LAUNCH_FUSED(8);
     else if (depth == 16) P2PFL_LAUNCH_FUSED(16);
-    else P2PFL_LAUNCH_FUSED(8);
+    else P2PFL_LAUNCH_FUSED(4);
 #undef P2PFL_LAUNCH_FUSED
     P2PFL_RETURN_LAST_ERROR();
 }

@@ -31,6 +31,19 @@ def pytest_collection_modifyitems(config, items):
 
 
 @pytest.fixture(autouse=True)
+def _seed_per_test(request):
+    """Random test data must not depend on which tests ran before: a GPU test draws from torch's global generators, so
+    adding or deselecting one case shifted the data of every later case (and a marginal tolerance elsewhere failed).
+    Every GPU test starts from a seed derived from its own id."""
+    if "gpu" in request.keywords:
+        import zlib
+
+        import torch
+        torch.manual_seed(zlib.crc32(request.node.nodeid.encode()) & 0x7fffffff)
+    yield
+
+
+@pytest.fixture(autouse=True)
 def _stream_watchdog(request):
     """If a GPU test runs longer than P2PFL_STREAM_WATCHDOG seconds (default 180, 0 = off), report which HIP
     streams still hold work (the engines' auxiliary streams and the default stream) and leave - a stalled

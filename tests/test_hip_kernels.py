@@ -914,8 +914,9 @@ def test_linear_head_matches_torch(K, B, nv, In, C, mask, kind, form):
             for q, mm in ((pw, W(m0)[k]), (pb, Bv(m0)[k])):
                 o.state[q] = {"momentum_buffer": mm.clone()}
         o.step()
-        assert torch.allclose(W(p)[k], pw.detach(), rtol=1e-5, atol=1e-6)
-        assert torch.allclose(Bv(p)[k], pb.detach(), rtol=1e-5, atol=1e-6)
+        # (+ 2e-4 of the step itself: where sqrt(v) is tiny a gradient that is right to 2e-5 moves the parameter visibly)
+        for ours, ref, start in ((W(p)[k], pw.detach(), W(p0)[k]), (Bv(p)[k], pb.detach(), Bv(p0)[k])):
+            assert ((ours - ref).abs() <= 1e-6 + 1e-5 * ref.abs() + 2e-4 * (ref - start).abs()).all()
         st = o.state[pw]
         assert rel_err(W(m)[k], st["exp_avg" if kind == "adam" else "momentum_buffer"]) < 2e-5
         if kind == "adam":
